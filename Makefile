@@ -1,0 +1,34 @@
+# Builds the drop-in C-ABI library (HIP kernels for gfx950 + C host planner).
+#   make            -> fftw3_amd/lib/libfftw3_amd.so (+ libfftw3.so.3 alias)
+#   make oracle     -> oracle/liboracle.so (CPU restatement, test infrastructure)
+HIPCC ?= /opt/rocm/bin/hipcc
+CC ?= gcc
+ARCH ?= gfx950
+CSRC := fftw3_amd/csrc
+LIBDIR := fftw3_amd/lib
+CFLAGS := -O2 -fPIC -std=gnu99 -Wall -Wextra -Iinclude -I$(CSRC)
+HIPFLAGS := -O3 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -std=c++17 -Wall
+
+OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/hostmath.o $(CSRC)/kernels.o
+
+all: $(LIBDIR)/libfftw3_amd.so
+
+$(CSRC)/%.o: $(CSRC)/%.c $(CSRC)/fa_plan.h $(CSRC)/fa_hip.h include/fftw3.h include/fftw3_amd.h
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(CSRC)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_amd.h $(wildcard $(CSRC)/*.hpp)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libfftw3_amd.so: $(OBJS)
+	mkdir -p $(LIBDIR)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lm
+	ln -sf libfftw3_amd.so $(LIBDIR)/libfftw3.so.3
+	ln -sf libfftw3_amd.so $(LIBDIR)/libfftw3.so
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(OBJS) $(LIBDIR)/*.so*
+
+.PHONY: all oracle clean

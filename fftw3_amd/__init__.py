@@ -1,0 +1,386 @@
+"""fftw3_amd -- Python host mirror of the FFTW3 C API over libfftw3_amd.so.
+
+The product is the C-ABI shared library built from ``fftw3_amd/csrc`` (HIP
+kernels for gfx950 + C planner).  This module is a thin ctypes binding whose
+function names and argument order mirror the reference API
+(reference ``fftw/fftw3.h:144-463``), so that tests read like FFTW client code:
+
+    p = fftw3_amd.plan_many_dft(1, [n], howmany, x, None, 1, n, y, None, 1, n,
+                                fftw3_amd.FORWARD, fftw3_amd.ESTIMATE)
+    p.execute()
+
+Arrays may be numpy arrays (host memory: staged through PCIe by the library),
+torch tensors (device memory: transformed in place in HBM) or raw integer
+addresses.  There is no Python or CPU fallback: if the shared library is
+missing the import fails, and executing without a HIP device raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libfftw3_amd.so")
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        "fftw3_amd: %s not found. Build it with `make` (or __graft_entry__.build()); "
+        "there is no fallback implementation." % _LIB_PATH)
+
+lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+
+FORWARD = -1
+BACKWARD = +1
+MEASURE = 0
+DESTROY_INPUT = 1 << 0
+UNALIGNED = 1 << 1
+CONSERVE_MEMORY = 1 << 2
+EXHAUSTIVE = 1 << 3
+PRESERVE_INPUT = 1 << 4
+PATIENT = 1 << 5
+ESTIMATE = 1 << 6
+WISDOM_ONLY = 1 << 21
+
+MAX_DIMS = 8
+MAX_RADICES = 16
+
+STEP_PASS, STEP_COPY, STEP_R2C_POST, STEP_C2R_PRE, STEP_RADER_MUL, STEP_HERM_EXPAND = 1, 2, 3, 4, 5, 6
+F_SWAP_IN, F_SWAP_OUT, F_REAL_IN, F_REAL_OUT = 1, 2, 4, 8
+F_MUL_TABLE, F_MUL_CONJ, F_PERM_SRC, F_PERM_DST, F_CONJ_OUT = 16, 32, 64, 128, 256
+
+
+class StepDesc(C.Structure):
+    """Mirror of fftw_amd_step_desc (include/fftw3_amd.h)."""
+    _fields_ = [
+        ("kind", C.c_int), ("src_buf", C.c_int), ("dst_buf", C.c_int),
+        ("src_base", C.c_longlong), ("dst_base", C.c_longlong),
+        ("src_im", C.c_longlong), ("dst_im", C.c_longlong),
+        ("flags", C.c_int), ("L", C.c_int),
+        ("nradices", C.c_int), ("radices", C.c_int * MAX_RADICES),
+        ("is_l", C.c_longlong), ("os_l", C.c_longlong),
+        ("ndims", C.c_int),
+        ("dim_n", C.c_longlong * MAX_DIMS), ("dim_is", C.c_longlong * MAX_DIMS),
+        ("dim_os", C.c_longlong * MAX_DIMS), ("dim_tw", C.c_longlong * MAX_DIMS),
+        ("tw_n", C.c_longlong),
+        ("tw_shift", C.c_int), ("tw_lo", C.c_int), ("tw_hi", C.c_int),
+        ("tile", C.c_int), ("batch_dim", C.c_int),
+        ("aux_n", C.c_longlong), ("aux_valid", C.c_longlong),
+        ("table", C.c_int), ("table2", C.c_int),
+        ("aux_buf", C.c_int), ("aux_base", C.c_longlong),
+        ("variant", C.c_int),
+    ]
+
+
+class iodim64(C.Structure):
+    _fields_ = [("n", C.c_ssize_t), ("is_", C.c_ssize_t), ("os", C.c_ssize_t)]
+
+
+_vp = C.c_void_p
+_ip = C.POINTER(C.c_int)
+
+
+def _sig(name, res, *args):
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = list(args)
+    return f
+
+
+_sig("fftw_execute", None, _vp)
+_sig("fftw_execute_dft", None, _vp, _vp, _vp)
+_sig("fftw_execute_split_dft", None, _vp, _vp, _vp, _vp, _vp)
+_sig("fftw_execute_dft_r2c", None, _vp, _vp, _vp)
+_sig("fftw_execute_dft_c2r", None, _vp, _vp, _vp)
+_sig("fftw_plan_dft", _vp, C.c_int, _ip, _vp, _vp, C.c_int, C.c_uint)
+_sig("fftw_plan_dft_1d", _vp, C.c_int, _vp, _vp, C.c_int, C.c_uint)
+_sig("fftw_plan_dft_2d", _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_uint)
+_sig("fftw_plan_dft_3d", _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_uint)
+_sig("fftw_plan_many_dft", _vp, C.c_int, _ip, C.c_int, _vp, _ip, C.c_int, C.c_int,
+     _vp, _ip, C.c_int, C.c_int, C.c_int, C.c_uint)
+_sig("fftw_plan_many_dft_r2c", _vp, C.c_int, _ip, C.c_int, _vp, _ip, C.c_int, C.c_int,
+     _vp, _ip, C.c_int, C.c_int, C.c_uint)
+_sig("fftw_plan_many_dft_c2r", _vp, C.c_int, _ip, C.c_int, _vp, _ip, C.c_int, C.c_int,
+     _vp, _ip, C.c_int, C.c_int, C.c_uint)
+_sig("fftw_plan_dft_r2c", _vp, C.c_int, _ip, _vp, _vp, C.c_uint)
+_sig("fftw_plan_dft_c2r", _vp, C.c_int, _ip, _vp, _vp, C.c_uint)
+_sig("fftw_plan_dft_r2c_1d", _vp, C.c_int, _vp, _vp, C.c_uint)
+_sig("fftw_plan_dft_c2r_1d", _vp, C.c_int, _vp, _vp, C.c_uint)
+_sig("fftw_plan_dft_r2c_2d", _vp, C.c_int, C.c_int, _vp, _vp, C.c_uint)
+_sig("fftw_plan_dft_c2r_2d", _vp, C.c_int, C.c_int, _vp, _vp, C.c_uint)
+_sig("fftw_plan_dft_r2c_3d", _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_uint)
+_sig("fftw_plan_dft_c2r_3d", _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_uint)
+_sig("fftw_plan_guru64_dft", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.POINTER(iodim64),
+     _vp, _vp, C.c_int, C.c_uint)
+_sig("fftw_plan_guru64_split_dft", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.POINTER(iodim64),
+     _vp, _vp, _vp, _vp, C.c_uint)
+_sig("fftw_plan_guru64_dft_r2c", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.POINTER(iodim64),
+     _vp, _vp, C.c_uint)
+_sig("fftw_plan_guru64_dft_c2r", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.POINTER(iodim64),
+     _vp, _vp, C.c_uint)
+_sig("fftw_destroy_plan", None, _vp)
+_sig("fftw_cleanup", None)
+_sig("fftw_malloc", _vp, C.c_size_t)
+_sig("fftw_free", None, _vp)
+_sig("fftw_sprint_plan", _vp, _vp)
+_sig("fftw_flops", None, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+_sig("fftw_amd_device_count", C.c_int)
+_sig("fftw_amd_malloc_device", _vp, C.c_size_t)
+_sig("fftw_amd_free_device", None, _vp)
+_sig("fftw_amd_plan_set_stream", None, _vp, _vp)
+_sig("fftw_amd_plan_sync", None, _vp)
+_sig("fftw_amd_plan_workspace_bytes", C.c_size_t, _vp)
+_sig("fftw_amd_set_chunk_bytes", None, C.c_size_t)
+_sig("fftw_amd_plan_num_steps", C.c_int, _vp)
+_sig("fftw_amd_plan_get_step", C.c_int, _vp, C.c_int, C.POINTER(StepDesc))
+_sig("fftw_amd_plan_chunk", C.c_longlong, _vp)
+_sig("fftw_amd_plan_batch", C.c_longlong, _vp)
+_sig("fftw_amd_plan_table", C.c_longlong, _vp, C.c_int, C.POINTER(C.c_double), C.c_longlong)
+_sig("fftw_amd_cexp", None, C.c_longlong, C.c_longlong, C.POINTER(C.c_double))
+_sig("fftw_amd_find_generator", C.c_longlong, C.c_longlong)
+_sig("fftw_amd_power_mod", C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong)
+_sig("fftw_amd_factor_passes", C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_longlong))
+_libc_free = C.CDLL(None).free
+_libc_free.argtypes = [_vp]
+
+
+def device_count():
+    return lib.fftw_amd_device_count()
+
+
+def ptr(x):
+    """Address of an array-like: numpy array, torch tensor, int or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if hasattr(x, "ctypes"):
+        return x.ctypes.data
+    raise TypeError("cannot take the address of %r" % type(x))
+
+
+def _ints(v):
+    if v is None:
+        return None
+    v = list(v)
+    return (C.c_int * len(v))(*v)
+
+
+def _current_stream_of(*arrays):
+    for a in arrays:
+        if hasattr(a, "data_ptr") and getattr(a, "is_cuda", False):
+            import torch
+            return torch.cuda.current_stream(a.device).cuda_stream
+    return None
+
+
+class Plan(object):
+    """Owns one fftw_plan.  Keeps the arrays alive that it was planned on."""
+
+    def __init__(self, handle, keep=()):
+        if not handle:
+            raise ValueError("FFTW planner returned NULL (invalid or unsupported problem)")
+        self.handle = handle
+        self._keep = keep
+        s = _current_stream_of(*keep)
+        if s:
+            lib.fftw_amd_plan_set_stream(self.handle, s)
+
+    def _need_device(self):
+        if device_count() <= 0:
+            raise RuntimeError("fftw3_amd: no HIP device; the executor has no CPU fallback")
+
+    def set_stream(self, hip_stream):
+        lib.fftw_amd_plan_set_stream(self.handle, hip_stream)
+
+    def execute(self):
+        self._need_device()
+        lib.fftw_execute(self.handle)
+
+    def execute_dft(self, i, o):
+        self._need_device()
+        lib.fftw_execute_dft(self.handle, ptr(i), ptr(o))
+
+    def execute_split_dft(self, ri, ii, ro, io):
+        self._need_device()
+        lib.fftw_execute_split_dft(self.handle, ptr(ri), ptr(ii), ptr(ro), ptr(io))
+
+    def execute_dft_r2c(self, i, o):
+        self._need_device()
+        lib.fftw_execute_dft_r2c(self.handle, ptr(i), ptr(o))
+
+    def execute_dft_c2r(self, i, o):
+        self._need_device()
+        lib.fftw_execute_dft_c2r(self.handle, ptr(i), ptr(o))
+
+    def sync(self):
+        lib.fftw_amd_plan_sync(self.handle)
+
+    def sprint(self):
+        p = lib.fftw_sprint_plan(self.handle)
+        s = C.string_at(p).decode()
+        _libc_free(p)
+        return s
+
+    def flops(self):
+        a, m, f = C.c_double(), C.c_double(), C.c_double()
+        lib.fftw_flops(self.handle, C.byref(a), C.byref(m), C.byref(f))
+        return a.value, m.value, f.value
+
+    @property
+    def batch(self):
+        return lib.fftw_amd_plan_batch(self.handle)
+
+    @property
+    def chunk(self):
+        return lib.fftw_amd_plan_chunk(self.handle)
+
+    @property
+    def workspace_bytes(self):
+        return lib.fftw_amd_plan_workspace_bytes(self.handle)
+
+    def steps(self):
+        out = []
+        for i in range(lib.fftw_amd_plan_num_steps(self.handle)):
+            d = StepDesc()
+            lib.fftw_amd_plan_get_step(self.handle, i, C.byref(d))
+            out.append(d)
+        return out
+
+    def table(self, tid):
+        """(kind-agnostic) host copy of table `tid` as a float64 numpy array, or
+        ('dft_of', src_id) when the device has yet to compute it."""
+        import numpy as np
+        probe = (C.c_double * 1)()
+        n = lib.fftw_amd_plan_table(self.handle, tid, probe, 1)
+        if n == 0:
+            return ("dft_of", int(probe[0]))
+        buf = np.empty(n, dtype=np.float64)
+        lib.fftw_amd_plan_table(self.handle, tid, buf.ctypes.data_as(C.POINTER(C.c_double)), n)
+        return buf
+
+    def destroy(self):
+        if self.handle:
+            lib.fftw_destroy_plan(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+# ---- planners, same names and argument order as the C API -----------------
+
+def plan_dft(rank, n, i, o, sign, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft(rank, _ints(n), ptr(i), ptr(o), sign, flags), (i, o))
+
+
+def plan_dft_1d(n, i, o, sign, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_1d(n, ptr(i), ptr(o), sign, flags), (i, o))
+
+
+def plan_dft_2d(n0, n1, i, o, sign, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_2d(n0, n1, ptr(i), ptr(o), sign, flags), (i, o))
+
+
+def plan_dft_3d(n0, n1, n2, i, o, sign, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_3d(n0, n1, n2, ptr(i), ptr(o), sign, flags), (i, o))
+
+
+def plan_many_dft(rank, n, howmany, i, inembed, istride, idist, o, onembed, ostride, odist,
+                  sign, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_many_dft(rank, _ints(n), howmany, ptr(i), _ints(inembed), istride,
+                                       idist, ptr(o), _ints(onembed), ostride, odist, sign, flags),
+                (i, o))
+
+
+def plan_many_dft_r2c(rank, n, howmany, i, inembed, istride, idist, o, onembed, ostride, odist,
+                      flags=ESTIMATE):
+    return Plan(lib.fftw_plan_many_dft_r2c(rank, _ints(n), howmany, ptr(i), _ints(inembed),
+                                           istride, idist, ptr(o), _ints(onembed), ostride, odist,
+                                           flags), (i, o))
+
+
+def plan_many_dft_c2r(rank, n, howmany, i, inembed, istride, idist, o, onembed, ostride, odist,
+                      flags=ESTIMATE):
+    return Plan(lib.fftw_plan_many_dft_c2r(rank, _ints(n), howmany, ptr(i), _ints(inembed),
+                                           istride, idist, ptr(o), _ints(onembed), ostride, odist,
+                                           flags), (i, o))
+
+
+def plan_dft_r2c(rank, n, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_r2c(rank, _ints(n), ptr(i), ptr(o), flags), (i, o))
+
+
+def plan_dft_c2r(rank, n, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_c2r(rank, _ints(n), ptr(i), ptr(o), flags), (i, o))
+
+
+def plan_dft_r2c_1d(n, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_r2c_1d(n, ptr(i), ptr(o), flags), (i, o))
+
+
+def plan_dft_c2r_1d(n, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_c2r_1d(n, ptr(i), ptr(o), flags), (i, o))
+
+
+def plan_dft_r2c_2d(n0, n1, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_r2c_2d(n0, n1, ptr(i), ptr(o), flags), (i, o))
+
+
+def plan_dft_c2r_2d(n0, n1, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_c2r_2d(n0, n1, ptr(i), ptr(o), flags), (i, o))
+
+
+def plan_dft_r2c_3d(n0, n1, n2, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_r2c_3d(n0, n1, n2, ptr(i), ptr(o), flags), (i, o))
+
+
+def plan_dft_c2r_3d(n0, n1, n2, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_dft_c2r_3d(n0, n1, n2, ptr(i), ptr(o), flags), (i, o))
+
+
+def _iodims(dims):
+    arr = (iodim64 * max(1, len(dims)))()
+    for k, (n, is_, os_) in enumerate(dims):
+        arr[k].n, arr[k].is_, arr[k].os = n, is_, os_
+    return arr
+
+
+def plan_guru64_dft(dims, howmany_dims, i, o, sign, flags=ESTIMATE):
+    """dims / howmany_dims: sequences of (n, is, os) in complex elements."""
+    return Plan(lib.fftw_plan_guru64_dft(len(dims), _iodims(dims), len(howmany_dims),
+                                         _iodims(howmany_dims), ptr(i), ptr(o), sign, flags), (i, o))
+
+
+def plan_guru64_split_dft(dims, howmany_dims, ri, ii, ro, io, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_guru64_split_dft(len(dims), _iodims(dims), len(howmany_dims),
+                                               _iodims(howmany_dims), ptr(ri), ptr(ii), ptr(ro),
+                                               ptr(io), flags), (ri, ii, ro, io))
+
+
+def plan_guru64_dft_r2c(dims, howmany_dims, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_guru64_dft_r2c(len(dims), _iodims(dims), len(howmany_dims),
+                                             _iodims(howmany_dims), ptr(i), ptr(o), flags), (i, o))
+
+
+def plan_guru64_dft_c2r(dims, howmany_dims, i, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_guru64_dft_c2r(len(dims), _iodims(dims), len(howmany_dims),
+                                             _iodims(howmany_dims), ptr(i), ptr(o), flags), (i, o))
+
+
+def cexp(m, n):
+    out = (C.c_double * 2)()
+    lib.fftw_amd_cexp(m, n, out)
+    return out[0], out[1]
+
+
+def factor_passes(n, max_passes=4):
+    lens = (C.c_longlong * 8)()
+    k = lib.fftw_amd_factor_passes(n, max_passes, lens)
+    return [lens[j] for j in range(k)]
+
+
+def set_chunk_bytes(nbytes):
+    lib.fftw_amd_set_chunk_bytes(nbytes)

@@ -1,0 +1,597 @@
+/*
+ * api.c -- the FFTW3 C API on top of the GPU planner.
+ *
+ * Argument meaning, defaults and error behaviour follow the reference API
+ * layer (fftw/fftw_api.c:1-1516); citations per function.  Errors are
+ * reported the FFTW way: planners return NULL, internal failures abort().
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fa_plan.h"
+#include "fa_hip.h"
+
+typedef struct fftw_plan_s plan;
+
+const char fftw_version[] = "fftw3-amd-0.1 (MI355X/gfx950 HIP executor, FFTW 3.3 API)";
+const char fftw_cc[] = "hipcc --offload-arch=gfx950";
+const char fftw_codelet_optim[] = "";
+
+/* ------------------------------------------------------------ helpers */
+
+/* offset range touched by a strided tensor, relative to its base */
+static void span_of(const fa_dim *d, int nd, int use_os, i64 *lo, i64 *hi) {
+    int i;
+    for (i = 0; i < nd; ++i) {
+        i64 s = use_os ? d[i].os : d[i].is;
+        i64 e = (d[i].n - 1) * s;
+        if (d[i].n <= 0) continue;
+        if (e < 0) *lo += e; else *hi += e;
+    }
+}
+
+static plan *finish(plan *p, double *ri, double *ii, double *ro, double *io) {
+    i64 cnt = 1;
+    int i;
+    p->ri = ri; p->ii = ii; p->ro = ro; p->io = io;
+    p->inplace = (ri == ro);
+    p->in_lo = p->in_hi = p->out_lo = p->out_hi = 0;
+    span_of(p->dims, p->rank, 0, &p->in_lo, &p->in_hi);
+    span_of(p->hdims, p->hrank, 0, &p->in_lo, &p->in_hi);
+    span_of(p->dims, p->rank, 1, &p->out_lo, &p->out_hi);
+    span_of(p->hdims, p->hrank, 1, &p->out_lo, &p->out_hi);
+    if (p->type == FA_R2C && p->rank > 0) {
+        /* the complex side has n/2+1 entries along the last dim */
+        i64 nl = p->dims[p->rank - 1].n, s = p->dims[p->rank - 1].os;
+        i64 full = (nl - 1) * s, half = (nl / 2) * s;
+        if (s >= 0) p->out_hi += half - full; else p->out_lo += half - full;
+    }
+    if (p->type == FA_C2R && p->rank > 0) {
+        i64 nl = p->dims[p->rank - 1].n, s = p->dims[p->rank - 1].is;
+        i64 full = (nl - 1) * s, half = (nl / 2) * s;
+        if (s >= 0) p->in_hi += half - full; else p->in_lo += half - full;
+    }
+    for (i = 0; i < p->rank; ++i) {
+        i64 e = p->dims[i].n;
+        if (p->type == FA_R2C && i == p->rank - 1) e = e / 2 + 1;
+        cnt *= e;
+    }
+    for (i = 0; i < p->hrank; ++i) cnt *= p->hdims[i].n;
+    p->out_written = (p->type == FA_C2R) ? cnt : 2 * cnt;
+    if (fa_build(p)) { fa_plan_free(p); return NULL; }
+    return p;
+}
+
+/* in-place transforms must map every element onto itself
+   (reference fftw_mkproblem_dft_d rejects the rest: fftw/fftw_api.c:4090-4094) */
+static int inplace_ok_c2c(const plan *p) {
+    int i;
+    for (i = 0; i < p->rank; ++i) if (p->dims[i].is != p->dims[i].os) return 0;
+    for (i = 0; i < p->hrank; ++i) if (p->hdims[i].is != p->hdims[i].os) return 0;
+    return 1;
+}
+
+/* move the loop with the largest stride to hdims[0]: it is the chunked batch */
+static void pick_batch(plan *p) {
+    int i, best = 0;
+    fa_dim t;
+    if (p->hrank < 2) return;
+    for (i = 1; i < p->hrank; ++i) {
+        i64 a = p->hdims[i].is < 0 ? -p->hdims[i].is : p->hdims[i].is;
+        i64 b = p->hdims[best].is < 0 ? -p->hdims[best].is : p->hdims[best].is;
+        if (a > b) best = i;
+    }
+    t = p->hdims[0]; p->hdims[0] = p->hdims[best]; p->hdims[best] = t;
+}
+
+static int dims_ok(int rank, const fftw_iodim64 *d) {
+    int i;
+    if (rank < 0 || rank > FA_MAXRANK) return 0;
+    for (i = 0; i < rank; ++i) if (d[i].n <= 0) return 0;
+    return 1;
+}
+
+static int hdims_ok(int rank, const fftw_iodim64 *d) {
+    int i;
+    if (rank < 0 || rank > FA_MAXRANK) return 0;
+    for (i = 0; i < rank; ++i) if (d[i].n < 0) return 0;
+    return 1;
+}
+
+/* common constructor: dims/hdims strides in units of the element type of each
+   side; mul_i / mul_o convert them to doubles (2 for complex, 1 for real) */
+static plan *mk_guru(int type, int rank, const fftw_iodim64 *dims, int hrank,
+                     const fftw_iodim64 *hdims, double *ri, double *ii, double *ro, double *io,
+                     int mul_i, int mul_o, int sign, unsigned flags) {
+    plan *p;
+    int i, k = 0;
+    if (!dims_ok(rank, dims) || !hdims_ok(hrank, hdims)) return NULL;
+    if ((type != FA_C2C) && rank < 1) return NULL;
+    p = fa_plan_new();
+    if (!p) return NULL;
+    p->type = type;
+    p->sign = sign;
+    p->flags = flags;
+    p->rank = rank;
+    for (i = 0; i < rank; ++i) {
+        p->dims[i].n = dims[i].n;
+        p->dims[i].is = dims[i].is * mul_i;
+        p->dims[i].os = dims[i].os * mul_o;
+    }
+    for (i = 0; i < hrank; ++i) {
+        if (hdims[i].n == 1) continue;          /* extent-1 loops carry nothing */
+        p->hdims[k].n = hdims[i].n;
+        p->hdims[k].is = hdims[i].is * mul_i;
+        p->hdims[k].os = hdims[i].os * mul_o;
+        ++k;
+    }
+    p->hrank = k;
+    pick_batch(p);
+    p->in_im = (type == FA_R2C) ? 0 : (i64)(ii - ri);
+    p->out_im = (type == FA_C2R) ? 0 : (i64)(io - ro);
+    if (type == FA_C2C && ri == ro && !inplace_ok_c2c(p)) { fa_plan_free(p); return NULL; }
+    if (type != FA_C2C && (void *)ri == (void *)ro) {
+        /* in-place real transforms always pass through scratch; when the two
+           layouts do not advance together per batch element, run the whole
+           batch as one chunk so every read precedes every write */
+        int same = 1;
+        for (i = 0; i < p->hrank; ++i) if (p->hdims[i].is != p->hdims[i].os) same = 0;
+        p->single_chunk = !same;
+        return finish(p, ri, ii, ro, io);
+    }
+    return finish(p, ri, ii, ro, io);
+}
+
+static void to64(int rank, const fftw_iodim *d, fftw_iodim64 *o) {
+    int i;
+    for (i = 0; i < rank && i < FA_MAXRANK; ++i) { o[i].n = d[i].n; o[i].is = d[i].is; o[i].os = d[i].os; }
+}
+
+/* row-major dims with physical (embedding) sizes -> strides
+   (reference fftw_mktensor_rowmajor, fftw/fftw_api.c:842-861) */
+static void rowmajor(int rank, const int *n, const int *niphys, const int *nophys,
+                     i64 is, i64 os, fftw_iodim64 *d) {
+    int i;
+    if (rank <= 0) return;
+    d[rank - 1].n = n[rank - 1];
+    d[rank - 1].is = is;
+    d[rank - 1].os = os;
+    for (i = rank - 1; i > 0; --i) {
+        d[i - 1].n = n[i - 1];
+        d[i - 1].is = d[i].is * niphys[i];
+        d[i - 1].os = d[i].os * nophys[i];
+    }
+}
+
+static int many_ok(int rank, const int *n, int howmany) {
+    int i;
+    if (howmany < 0 || rank < 0 || rank > FA_MAXRANK) return 0;   /* fftw_many_kosherp A.c:863-877 */
+    for (i = 0; i < rank; ++i) if (n[i] <= 0) return 0;
+    return 1;
+}
+
+/* default embedding of a real-data transform (reference fftw_rdft2_pad,
+   fftw/fftw_api.c:774-788): the complex side always has n/2+1 along the last
+   dim; the real side is padded to 2(n/2+1) only when in place */
+static const int *rdft2_pad(int rank, const int *n, const int *nembed, int inplace, int cmplx,
+                            int *store) {
+    if (!nembed && rank > 0) {
+        if (inplace || cmplx) {
+            memcpy(store, n, sizeof(int) * (size_t)rank);
+            store[rank - 1] = (n[rank - 1] / 2 + 1) * (cmplx ? 1 : 2);
+            return store;
+        }
+        return n;
+    }
+    return nembed;
+}
+
+/* ------------------------------------------------- complex DFT planners */
+
+fftw_plan fftw_plan_many_dft(int rank, const int *n, int howmany,
+                             fftw_complex *in, const int *inembed, int istride, int idist,
+                             fftw_complex *out, const int *onembed, int ostride, int odist,
+                             int sign, unsigned flags) {
+    fftw_iodim64 d[FA_MAXRANK], h;
+    if (!many_ok(rank, n, howmany)) return NULL;
+    rowmajor(rank, n, inembed ? inembed : n, onembed ? onembed : n, istride, ostride, d);
+    h.n = howmany; h.is = idist; h.os = odist;
+    return mk_guru(FA_C2C, rank, d, 1, &h, (double *)in, (double *)in + 1,
+                   (double *)out, (double *)out + 1, 2, 2, sign, flags);
+}
+
+fftw_plan fftw_plan_dft(int rank, const int *n, fftw_complex *in, fftw_complex *out,
+                        int sign, unsigned flags) {
+    return fftw_plan_many_dft(rank, n, 1, in, 0, 1, 1, out, 0, 1, 1, sign, flags);
+}
+
+fftw_plan fftw_plan_dft_1d(int n, fftw_complex *in, fftw_complex *out, int sign, unsigned flags) {
+    return fftw_plan_dft(1, &n, in, out, sign, flags);
+}
+
+fftw_plan fftw_plan_dft_2d(int n0, int n1, fftw_complex *in, fftw_complex *out,
+                           int sign, unsigned flags) {
+    int n[2];
+    n[0] = n0; n[1] = n1;
+    return fftw_plan_dft(2, n, in, out, sign, flags);
+}
+
+fftw_plan fftw_plan_dft_3d(int n0, int n1, int n2, fftw_complex *in, fftw_complex *out,
+                           int sign, unsigned flags) {
+    int n[3];
+    n[0] = n0; n[1] = n1; n[2] = n2;
+    return fftw_plan_dft(3, n, in, out, sign, flags);
+}
+
+fftw_plan fftw_plan_guru64_dft(int rank, const fftw_iodim64 *dims, int howmany_rank,
+                               const fftw_iodim64 *howmany_dims, fftw_complex *in,
+                               fftw_complex *out, int sign, unsigned flags) {
+    return mk_guru(FA_C2C, rank, dims, howmany_rank, howmany_dims, (double *)in, (double *)in + 1,
+                   (double *)out, (double *)out + 1, 2, 2, sign, flags);
+}
+
+fftw_plan fftw_plan_guru_dft(int rank, const fftw_iodim *dims, int howmany_rank,
+                             const fftw_iodim *howmany_dims, fftw_complex *in, fftw_complex *out,
+                             int sign, unsigned flags) {
+    fftw_iodim64 d[FA_MAXRANK], h[FA_MAXRANK];
+    if (rank < 0 || rank > FA_MAXRANK || howmany_rank < 0 || howmany_rank > FA_MAXRANK) return NULL;
+    to64(rank, dims, d);
+    to64(howmany_rank, howmany_dims, h);
+    return fftw_plan_guru64_dft(rank, d, howmany_rank, h, in, out, sign, flags);
+}
+
+/* split arrays: strides count doubles; the transform is always forward
+   (reference: "sign" of split plans is FFT_SIGN, fftw/fftw_api.c:1290-1330) */
+fftw_plan fftw_plan_guru64_split_dft(int rank, const fftw_iodim64 *dims, int howmany_rank,
+                                     const fftw_iodim64 *howmany_dims, double *ri, double *ii,
+                                     double *ro, double *io, unsigned flags) {
+    return mk_guru(FA_C2C, rank, dims, howmany_rank, howmany_dims, ri, ii, ro, io, 1, 1,
+                   FFTW_FORWARD, flags);
+}
+
+fftw_plan fftw_plan_guru_split_dft(int rank, const fftw_iodim *dims, int howmany_rank,
+                                   const fftw_iodim *howmany_dims, double *ri, double *ii,
+                                   double *ro, double *io, unsigned flags) {
+    fftw_iodim64 d[FA_MAXRANK], h[FA_MAXRANK];
+    if (rank < 0 || rank > FA_MAXRANK || howmany_rank < 0 || howmany_rank > FA_MAXRANK) return NULL;
+    to64(rank, dims, d);
+    to64(howmany_rank, howmany_dims, h);
+    return fftw_plan_guru64_split_dft(rank, d, howmany_rank, h, ri, ii, ro, io, flags);
+}
+
+/* ------------------------------------------------- real-data planners */
+
+fftw_plan fftw_plan_many_dft_r2c(int rank, const int *n, int howmany,
+                                 double *in, const int *inembed, int istride, int idist,
+                                 fftw_complex *out, const int *onembed, int ostride, int odist,
+                                 unsigned flags) {
+    fftw_iodim64 d[FA_MAXRANK], h;
+    int si[FA_MAXRANK], so[FA_MAXRANK], inplace;
+    const int *ni, *no;
+    if (!many_ok(rank, n, howmany) || rank < 1) return NULL;
+    inplace = ((void *)in == (void *)out);
+    ni = rdft2_pad(rank, n, inembed, inplace, 0, si);
+    no = rdft2_pad(rank, n, onembed, inplace, 1, so);
+    rowmajor(rank, n, ni, no, istride, ostride, d);
+    h.n = howmany; h.is = idist; h.os = odist;
+    return mk_guru(FA_R2C, rank, d, 1, &h, in, in, (double *)out, (double *)out + 1, 1, 2,
+                   FFTW_FORWARD, flags);
+}
+
+fftw_plan fftw_plan_dft_r2c(int rank, const int *n, double *in, fftw_complex *out, unsigned flags) {
+    return fftw_plan_many_dft_r2c(rank, n, 1, in, 0, 1, 1, out, 0, 1, 1, flags);
+}
+fftw_plan fftw_plan_dft_r2c_1d(int n, double *in, fftw_complex *out, unsigned flags) {
+    return fftw_plan_dft_r2c(1, &n, in, out, flags);
+}
+fftw_plan fftw_plan_dft_r2c_2d(int n0, int n1, double *in, fftw_complex *out, unsigned flags) {
+    int n[2];
+    n[0] = n0; n[1] = n1;
+    return fftw_plan_dft_r2c(2, n, in, out, flags);
+}
+fftw_plan fftw_plan_dft_r2c_3d(int n0, int n1, int n2, double *in, fftw_complex *out, unsigned flags) {
+    int n[3];
+    n[0] = n0; n[1] = n1; n[2] = n2;
+    return fftw_plan_dft_r2c(3, n, in, out, flags);
+}
+
+fftw_plan fftw_plan_many_dft_c2r(int rank, const int *n, int howmany,
+                                 fftw_complex *in, const int *inembed, int istride, int idist,
+                                 double *out, const int *onembed, int ostride, int odist,
+                                 unsigned flags) {
+    fftw_iodim64 d[FA_MAXRANK], h;
+    int si[FA_MAXRANK], so[FA_MAXRANK], inplace;
+    const int *ni, *no;
+    if (!many_ok(rank, n, howmany) || rank < 1) return NULL;
+    inplace = ((void *)in == (void *)out);
+    ni = rdft2_pad(rank, n, inembed, inplace, 1, si);
+    no = rdft2_pad(rank, n, onembed, inplace, 0, so);
+    rowmajor(rank, n, ni, no, istride, ostride, d);
+    h.n = howmany; h.is = idist; h.os = odist;
+    return mk_guru(FA_C2R, rank, d, 1, &h, (double *)in, (double *)in + 1, out, out, 2, 1,
+                   FFTW_BACKWARD, flags);
+}
+
+fftw_plan fftw_plan_dft_c2r(int rank, const int *n, fftw_complex *in, double *out, unsigned flags) {
+    return fftw_plan_many_dft_c2r(rank, n, 1, in, 0, 1, 1, out, 0, 1, 1, flags);
+}
+fftw_plan fftw_plan_dft_c2r_1d(int n, fftw_complex *in, double *out, unsigned flags) {
+    return fftw_plan_dft_c2r(1, &n, in, out, flags);
+}
+fftw_plan fftw_plan_dft_c2r_2d(int n0, int n1, fftw_complex *in, double *out, unsigned flags) {
+    int n[2];
+    n[0] = n0; n[1] = n1;
+    return fftw_plan_dft_c2r(2, n, in, out, flags);
+}
+fftw_plan fftw_plan_dft_c2r_3d(int n0, int n1, int n2, fftw_complex *in, double *out, unsigned flags) {
+    int n[3];
+    n[0] = n0; n[1] = n1; n[2] = n2;
+    return fftw_plan_dft_c2r(3, n, in, out, flags);
+}
+
+fftw_plan fftw_plan_guru64_dft_r2c(int rank, const fftw_iodim64 *dims, int howmany_rank,
+                                   const fftw_iodim64 *howmany_dims, double *in, fftw_complex *out,
+                                   unsigned flags) {
+    return mk_guru(FA_R2C, rank, dims, howmany_rank, howmany_dims, in, in, (double *)out,
+                   (double *)out + 1, 1, 2, FFTW_FORWARD, flags);
+}
+fftw_plan fftw_plan_guru64_dft_c2r(int rank, const fftw_iodim64 *dims, int howmany_rank,
+                                   const fftw_iodim64 *howmany_dims, fftw_complex *in, double *out,
+                                   unsigned flags) {
+    return mk_guru(FA_C2R, rank, dims, howmany_rank, howmany_dims, (double *)in, (double *)in + 1,
+                   out, out, 2, 1, FFTW_BACKWARD, flags);
+}
+fftw_plan fftw_plan_guru64_split_dft_r2c(int rank, const fftw_iodim64 *dims, int howmany_rank,
+                                         const fftw_iodim64 *howmany_dims, double *in, double *ro,
+                                         double *io, unsigned flags) {
+    return mk_guru(FA_R2C, rank, dims, howmany_rank, howmany_dims, in, in, ro, io, 1, 1,
+                   FFTW_FORWARD, flags);
+}
+fftw_plan fftw_plan_guru64_split_dft_c2r(int rank, const fftw_iodim64 *dims, int howmany_rank,
+                                         const fftw_iodim64 *howmany_dims, double *ri, double *ii,
+                                         double *out, unsigned flags) {
+    return mk_guru(FA_C2R, rank, dims, howmany_rank, howmany_dims, ri, ii, out, out, 1, 1,
+                   FFTW_BACKWARD, flags);
+}
+
+#define GURU32(name64, ...)                                                                   \
+    fftw_iodim64 d[FA_MAXRANK], h[FA_MAXRANK];                                                \
+    if (rank < 0 || rank > FA_MAXRANK || howmany_rank < 0 || howmany_rank > FA_MAXRANK)       \
+        return NULL;                                                                          \
+    to64(rank, dims, d);                                                                      \
+    to64(howmany_rank, howmany_dims, h);                                                      \
+    return name64(rank, d, howmany_rank, h, __VA_ARGS__)
+
+fftw_plan fftw_plan_guru_dft_r2c(int rank, const fftw_iodim *dims, int howmany_rank,
+                                 const fftw_iodim *howmany_dims, double *in, fftw_complex *out,
+                                 unsigned flags) {
+    GURU32(fftw_plan_guru64_dft_r2c, in, out, flags);
+}
+fftw_plan fftw_plan_guru_dft_c2r(int rank, const fftw_iodim *dims, int howmany_rank,
+                                 const fftw_iodim *howmany_dims, fftw_complex *in, double *out,
+                                 unsigned flags) {
+    GURU32(fftw_plan_guru64_dft_c2r, in, out, flags);
+}
+fftw_plan fftw_plan_guru_split_dft_r2c(int rank, const fftw_iodim *dims, int howmany_rank,
+                                       const fftw_iodim *howmany_dims, double *in, double *ro,
+                                       double *io, unsigned flags) {
+    GURU32(fftw_plan_guru64_split_dft_r2c, in, ro, io, flags);
+}
+fftw_plan fftw_plan_guru_split_dft_c2r(int rank, const fftw_iodim *dims, int howmany_rank,
+                                       const fftw_iodim *howmany_dims, double *ri, double *ii,
+                                       double *out, unsigned flags) {
+    GURU32(fftw_plan_guru64_split_dft_c2r, ri, ii, out, flags);
+}
+
+/* ---- r2r: outside the hot path; symbols kept so callers link */
+fftw_plan fftw_plan_many_r2r(int rank, const int *n, int howmany, double *in, const int *inembed,
+                             int istride, int idist, double *out, const int *onembed, int ostride,
+                             int odist, const fftw_r2r_kind *kind, unsigned flags) {
+    (void)rank; (void)n; (void)howmany; (void)in; (void)inembed; (void)istride; (void)idist;
+    (void)out; (void)onembed; (void)ostride; (void)odist; (void)kind; (void)flags;
+    return NULL;
+}
+fftw_plan fftw_plan_r2r(int rank, const int *n, double *in, double *out,
+                        const fftw_r2r_kind *kind, unsigned flags) {
+    (void)rank; (void)n; (void)in; (void)out; (void)kind; (void)flags;
+    return NULL;
+}
+fftw_plan fftw_plan_r2r_1d(int n, double *in, double *out, fftw_r2r_kind kind, unsigned flags) {
+    (void)n; (void)in; (void)out; (void)kind; (void)flags;
+    return NULL;
+}
+fftw_plan fftw_plan_r2r_2d(int n0, int n1, double *in, double *out, fftw_r2r_kind k0,
+                           fftw_r2r_kind k1, unsigned flags) {
+    (void)n0; (void)n1; (void)in; (void)out; (void)k0; (void)k1; (void)flags;
+    return NULL;
+}
+fftw_plan fftw_plan_r2r_3d(int n0, int n1, int n2, double *in, double *out, fftw_r2r_kind k0,
+                           fftw_r2r_kind k1, fftw_r2r_kind k2, unsigned flags) {
+    (void)n0; (void)n1; (void)n2; (void)in; (void)out; (void)k0; (void)k1; (void)k2; (void)flags;
+    return NULL;
+}
+fftw_plan fftw_plan_guru_r2r(int rank, const fftw_iodim *dims, int howmany_rank,
+                             const fftw_iodim *howmany_dims, double *in, double *out,
+                             const fftw_r2r_kind *kind, unsigned flags) {
+    (void)rank; (void)dims; (void)howmany_rank; (void)howmany_dims; (void)in; (void)out;
+    (void)kind; (void)flags;
+    return NULL;
+}
+fftw_plan fftw_plan_guru64_r2r(int rank, const fftw_iodim64 *dims, int howmany_rank,
+                               const fftw_iodim64 *howmany_dims, double *in, double *out,
+                               const fftw_r2r_kind *kind, unsigned flags) {
+    (void)rank; (void)dims; (void)howmany_rank; (void)howmany_dims; (void)in; (void)out;
+    (void)kind; (void)flags;
+    return NULL;
+}
+void fftw_execute_r2r(const fftw_plan p, double *in, double *out) {
+    (void)p; (void)in; (void)out;
+    fprintf(stderr, "fftw3_amd: r2r transforms are not implemented\n");
+    abort();
+}
+
+/* ------------------------------------------------------------ execution */
+
+/* reference fftw_execute, fftw/fftw_api.c:428-431 */
+void fftw_execute(const fftw_plan p) {
+    fa_run(p, p->ri, p->ii, p->ro, p->io);
+}
+
+/* new-array execution (reference fftw/fftw_api.c:434-440).  The arrays must
+   have the layout and in-placeness the plan was created with. */
+void fftw_execute_dft(const fftw_plan p, fftw_complex *in, fftw_complex *out) {
+    fa_run(p, (double *)in, (double *)in + 1, (double *)out, (double *)out + 1);
+}
+void fftw_execute_split_dft(const fftw_plan p, double *ri, double *ii, double *ro, double *io) {
+    fa_run(p, ri, ii, ro, io);
+}
+void fftw_execute_dft_r2c(const fftw_plan p, double *in, fftw_complex *out) {
+    fa_run(p, in, in, (double *)out, (double *)out + 1);
+}
+void fftw_execute_dft_c2r(const fftw_plan p, fftw_complex *in, double *out) {
+    fa_run(p, (double *)in, (double *)in + 1, out, out);
+}
+void fftw_execute_split_dft_r2c(const fftw_plan p, double *in, double *ro, double *io) {
+    fa_run(p, in, in, ro, io);
+}
+void fftw_execute_split_dft_c2r(const fftw_plan p, double *ri, double *ii, double *out) {
+    fa_run(p, ri, ii, out, out);
+}
+
+/* NULL-safe like the reference (fftw/fftw_api.c:409-410) */
+void fftw_destroy_plan(fftw_plan p) { fa_plan_free(p); }
+
+/* There is no global planner state to drop: plans own their tables. */
+void fftw_cleanup(void) {}
+void fftw_forget_wisdom(void) {}
+void fftw_set_timelimit(double t) { (void)t; }
+void fftw_plan_with_nthreads(int nthreads) { (void)nthreads; }
+int  fftw_init_threads(void) { return 1; }
+void fftw_cleanup_threads(void) {}
+void fftw_make_planner_thread_safe(void) {}
+
+/* ---- wisdom: the static planner has nothing to remember; the calls succeed
+   with an empty record so that callers which save/restore wisdom keep working */
+static const char wisdom_text[] = "(fftw3_amd_wisdom)\n";
+char *fftw_export_wisdom_to_string(void) {
+    char *s = (char *)malloc(sizeof(wisdom_text));
+    if (s) memcpy(s, wisdom_text, sizeof(wisdom_text));
+    return s;
+}
+void fftw_export_wisdom_to_file(FILE *f) { fputs(wisdom_text, f); }
+int fftw_export_wisdom_to_filename(const char *filename) {
+    FILE *f = fopen(filename, "w");
+    if (!f) return 0;
+    fputs(wisdom_text, f);
+    return fclose(f) == 0;
+}
+void fftw_export_wisdom(fftw_write_char_func w, void *data) {
+    const char *c;
+    for (c = wisdom_text; *c; ++c) w(*c, data);
+}
+int fftw_import_system_wisdom(void) { return 0; }
+int fftw_import_wisdom_from_filename(const char *filename) {
+    FILE *f = fopen(filename, "r");
+    if (!f) return 0;
+    fclose(f);
+    return 1;
+}
+int fftw_import_wisdom_from_file(FILE *f) { (void)f; return 1; }
+int fftw_import_wisdom_from_string(const char *s) { return s != NULL; }
+int fftw_import_wisdom(fftw_read_char_func r, void *data) { (void)r; (void)data; return 1; }
+
+/* ---- introspection */
+char *fftw_sprint_plan(const fftw_plan p) { return p ? fa_sprint(p) : NULL; }
+void fftw_fprint_plan(const fftw_plan p, FILE *f) {
+    char *s = fftw_sprint_plan(p);
+    if (s) { fputs(s, f); free(s); }
+}
+void fftw_print_plan(const fftw_plan p) { fftw_fprint_plan(p, stdout); }
+
+void fftw_flops(const fftw_plan p, double *add, double *mul, double *fmas) {
+    double total = p->est_flops * (p->chunk ? (double)p->batch / (double)p->chunk : 0.0);
+    *add = 0.6 * total;
+    *mul = 0.2 * total;
+    *fmas = 0.1 * total;
+}
+double fftw_estimate_cost(const fftw_plan p) {
+    double a, m, f;
+    fftw_flops(p, &a, &m, &f);
+    return a + m + 2 * f;
+}
+double fftw_cost(const fftw_plan p) { return fftw_estimate_cost(p); }
+
+/* ---- memory: pinned host memory when a device is present so that the
+   staged path runs at PCIe DMA speed; plain aligned memory otherwise */
+void *fftw_malloc(size_t n) {
+    void *p = fa_hip_host_malloc(n);
+    if (p) return p;
+    if (posix_memalign(&p, 64, n ? n : 64)) return NULL;
+    return p;
+}
+double *fftw_alloc_real(size_t n) { return (double *)fftw_malloc(n * sizeof(double)); }
+fftw_complex *fftw_alloc_complex(size_t n) { return (fftw_complex *)fftw_malloc(n * sizeof(fftw_complex)); }
+void fftw_free(void *p) {
+    if (!p) return;
+    if (!fa_hip_host_free(p)) free(p);
+}
+int fftw_alignment_of(double *p) { return (int)(((size_t)p) % 16); }
+
+/* ------------------------------------------------- fftw_amd_ extensions */
+
+int fftw_amd_device_count(void) { return fa_hip_device_count(); }
+void *fftw_amd_malloc_device(size_t nbytes) {
+    if (fa_hip_device_count() <= 0) return NULL;
+    return fa_hip_malloc(nbytes);
+}
+void fftw_amd_free_device(void *p) { fa_hip_free(p); }
+void fftw_amd_plan_set_stream(fftw_plan p, void *s) { if (p) p->stream = s; }
+void fftw_amd_plan_sync(fftw_plan p) { if (p && fa_hip_device_count() > 0) fa_hip_stream_sync(p->stream); }
+
+size_t fftw_amd_plan_workspace_bytes(const fftw_plan p) {
+    size_t b = 0;
+    int i;
+    for (i = 0; i < p->ntabs; ++i)
+        b += (size_t)p->tabs[i].len * (p->tabs[i].kind == FA_TAB_PERM ? sizeof(i64) : 16);
+    for (i = 2; i < p->nbufs; ++i) b += (size_t)p->buf_reals[i] * sizeof(double);
+    return b;
+}
+
+int fftw_amd_plan_num_steps(const fftw_plan p) { return p ? p->nsteps : 0; }
+int fftw_amd_plan_get_step(const fftw_plan p, int i, fftw_amd_step_desc *out) {
+    if (!p || i < 0 || i >= p->nsteps) return -1;
+    *out = p->steps[i];
+    return 0;
+}
+long long fftw_amd_plan_chunk(const fftw_plan p) { return p->chunk; }
+long long fftw_amd_plan_batch(const fftw_plan p) { return p->batch; }
+
+/* returns the length in doubles (int64 tables are reported as doubles holding
+   the integer values); negative kind-coded length -(src+1) - 1000000 is never
+   used: a table the device has yet to compute reports 0 and its source id in
+   dst[0] when cap >= 1 */
+long long fftw_amd_plan_table(const fftw_plan p, int id, double *dst, long long cap) {
+    const fa_table *t;
+    long long i, n;
+    if (!p || id < 0 || id >= p->ntabs) return -1;
+    t = &p->tabs[id];
+    if (t->kind == FA_TAB_PERM) {
+        n = t->len;
+        for (i = 0; i < n && i < cap; ++i) dst[i] = (double)((const i64 *)t->host)[i];
+        return n;
+    }
+    if (!t->host) {
+        if (cap >= 1) dst[0] = (double)t->src;
+        return 0;
+    }
+    n = 2 * t->len;
+    for (i = 0; i < n && i < cap; ++i) dst[i] = ((const double *)t->host)[i];
+    return n;
+}
+
+void fftw_amd_cexp(long long m, long long n, double out[2]) { fa_cexp(m, n, out); }
+long long fftw_amd_find_generator(long long p) { return fa_find_generator(p); }
+long long fftw_amd_power_mod(long long b, long long e, long long p) { return fa_power_mod(b, e, p); }
+int fftw_amd_factor_passes(long long n, int max_passes, long long *lens) {
+    return fa_factor_passes(n, max_passes, FA_LMAX_SINGLE, 1024, lens);
+}

@@ -1,0 +1,230 @@
+/*
+ * butterflies.h -- register-resident radix-r DFT butterflies for gfx950 (K7).
+ *
+ * These are the MI355X counterparts of the reference's no-twiddle codelets
+ * n1_2 .. n1_16 (reference fftw/dft_scalar/codelets/n1_*.c; codelet ABI
+ * fftw/fftw_api.h:1794-1795): straight-line forward DFTs of r complex doubles
+ * held in registers, one butterfly per work-item.  They are hand-written, not
+ * generated: radix 2/4/8/16 by explicit Cooley-Tukey splitting, the odd primes
+ * 3/5/7/11/13 by the symmetric (x_j +- x_{r-j}) formula that reference
+ * fftw/genfft/fft.ml:53-80 documents for prime sizes.
+ *
+ * Convention: forward transform, X[q] = sum_j x[j] exp(-2 pi i j q / r).
+ * Backward transforms are done by the callers with the (re,im) swap identity
+ * (reference fftw/fftw_api.c:14555-14564).
+ *
+ * The header has no HIP dependency beyond FA_DEV/cplx so that the host unit
+ * test (tests/test_butterflies.py) can compile it with g++.
+ */
+#ifndef FA_BUTTERFLIES_H
+#define FA_BUTTERFLIES_H
+
+#ifndef FA_DEV
+#define FA_DEV __device__ __forceinline__
+#endif
+
+#ifndef FA_CPLX_DEFINED
+#define FA_CPLX_DEFINED
+typedef double2 cplx;
+#endif
+
+FA_DEV cplx c_make(double a, double b) { cplx r; r.x = a; r.y = b; return r; }
+FA_DEV cplx c_add(cplx a, cplx b) { return c_make(a.x + b.x, a.y + b.y); }
+FA_DEV cplx c_sub(cplx a, cplx b) { return c_make(a.x - b.x, a.y - b.y); }
+/* a * w */
+FA_DEV cplx c_mul(cplx a, cplx w) { return c_make(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+/* a * conj(w): the forward-twiddle product, same form as reference t1_4.c:139-140 */
+FA_DEV cplx c_mulc(cplx a, cplx w) { return c_make(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y); }
+/* a * (-i) and a * (+i) */
+FA_DEV cplx c_mni(cplx a) { return c_make(a.y, -a.x); }
+FA_DEV cplx c_mpi(cplx a) { return c_make(-a.y, a.x); }
+FA_DEV cplx c_scale(cplx a, double s) { return c_make(a.x * s, a.y * s); }
+
+#define FA_SQRT1_2 0.70710678118654752440084436210484903928483593768847
+#define FA_COS_PI_8 0.92387953251128675612818318939678828682241662586364
+#define FA_SIN_PI_8 0.38268343236508977172845998403039886676134456248563
+
+template <int R> struct Bfly;
+
+template <> struct Bfly<1> {
+    static FA_DEV void run(cplx *) {}
+};
+
+template <> struct Bfly<2> {
+    static FA_DEV void run(cplx *x) {
+        cplx a = x[0];
+        x[0] = c_add(a, x[1]);
+        x[1] = c_sub(a, x[1]);
+    }
+};
+
+template <> struct Bfly<4> {
+    static FA_DEV void run(cplx *x) {
+        cplx a = c_add(x[0], x[2]), b = c_sub(x[0], x[2]);
+        cplx c = c_add(x[1], x[3]), d = c_mni(c_sub(x[1], x[3]));
+        x[0] = c_add(a, c);
+        x[2] = c_sub(a, c);
+        x[1] = c_add(b, d);
+        x[3] = c_sub(b, d);
+    }
+};
+
+template <> struct Bfly<8> {
+    static FA_DEV void run(cplx *x) {
+        cplx e[4] = { x[0], x[2], x[4], x[6] };
+        cplx o[4] = { x[1], x[3], x[5], x[7] };
+        Bfly<4>::run(e);
+        Bfly<4>::run(o);
+        /* o[k] *= w8^k, w8 = exp(-i pi/4) */
+        cplx t1 = c_make((o[1].x + o[1].y) * FA_SQRT1_2, (o[1].y - o[1].x) * FA_SQRT1_2);
+        cplx t2 = c_mni(o[2]);
+        cplx t3 = c_make((o[3].y - o[3].x) * FA_SQRT1_2, -(o[3].x + o[3].y) * FA_SQRT1_2);
+        x[0] = c_add(e[0], o[0]); x[4] = c_sub(e[0], o[0]);
+        x[1] = c_add(e[1], t1);   x[5] = c_sub(e[1], t1);
+        x[2] = c_add(e[2], t2);   x[6] = c_sub(e[2], t2);
+        x[3] = c_add(e[3], t3);   x[7] = c_sub(e[3], t3);
+    }
+};
+
+template <> struct Bfly<16> {
+    /* 16 = 4 x 4: input j = i + 4 j2, output k = k2 + 4 k1 */
+    static FA_DEV void run(cplx *x) {
+        cplx z[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            z[i][0] = x[i]; z[i][1] = x[i + 4]; z[i][2] = x[i + 8]; z[i][3] = x[i + 12];
+            Bfly<4>::run(z[i]);
+        }
+        /* twiddle z[i][k2] *= w16^(i k2) */
+        const cplx w1 = c_make(FA_COS_PI_8, FA_SIN_PI_8);   /* conj applied by c_mulc */
+        const cplx w2 = c_make(FA_SQRT1_2, FA_SQRT1_2);
+        const cplx w3 = c_make(FA_SIN_PI_8, FA_COS_PI_8);
+        z[1][1] = c_mulc(z[1][1], w1);
+        z[1][2] = c_mulc(z[1][2], w2);
+        z[1][3] = c_mulc(z[1][3], w3);
+        z[2][1] = c_mulc(z[2][1], w2);
+        z[2][2] = c_mni(z[2][2]);                            /* w16^4 = -i */
+        z[2][3] = c_mulc(z[2][3], c_make(-FA_SQRT1_2, FA_SQRT1_2)); /* w16^6 */
+        z[3][1] = c_mulc(z[3][1], w3);
+        z[3][2] = c_mulc(z[3][2], c_make(-FA_SQRT1_2, FA_SQRT1_2)); /* w16^6 */
+        z[3][3] = c_mulc(z[3][3], c_make(-FA_COS_PI_8, -FA_SIN_PI_8)); /* w16^9 */
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            cplx c[4] = { z[0][k2], z[1][k2], z[2][k2], z[3][k2] };
+            Bfly<4>::run(c);
+            x[k2] = c[0]; x[k2 + 4] = c[1]; x[k2 + 8] = c[2]; x[k2 + 12] = c[3];
+        }
+    }
+};
+
+/* ---- odd primes: symmetric formula ------------------------------------ */
+
+template <int R> struct OddTrig;
+template <> struct OddTrig<3> {
+    static FA_DEV double c(int k) { const double t[] = { 1.0, -0.5 }; return t[k]; }
+    static FA_DEV double s(int k) { const double t[] = { 0.0, 0.86602540378443864676372317075293618347140262690519 }; return t[k]; }
+};
+template <> struct OddTrig<5> {
+    static FA_DEV double c(int k) {
+        const double t[] = { 1.0, 0.30901699437494742410229341718281905886015458990289,
+                             -0.80901699437494742410229341718281905886015458990289 };
+        return t[k];
+    }
+    static FA_DEV double s(int k) {
+        const double t[] = { 0.0, 0.95105651629515357211643933337938214340569863412575,
+                             0.58778525229247312916870595463907276859765243764315 };
+        return t[k];
+    }
+};
+template <> struct OddTrig<7> {
+    static FA_DEV double c(int k) {
+        const double t[] = { 1.0, 0.62348980185873353052500488400423981063227473089640,
+                             -0.22252093395631440428890256449679475946635556876452,
+                             -0.90096886790241912623610231950744505116591916213185 };
+        return t[k];
+    }
+    static FA_DEV double s(int k) {
+        const double t[] = { 0.0, 0.78183148246802980870844452667405775023233451870869,
+                             0.97492791218182360701813168299393121723278580062000,
+                             0.43388373911755812047576833284835875460999072778746 };
+        return t[k];
+    }
+};
+template <> struct OddTrig<11> {
+    static FA_DEV double c(int k) {
+        const double t[] = { 1.0, 0.84125353283118116886181164892548537747900416427459,
+                             0.41541501300188642553467186187277594354271271181612,
+                             -0.14231483827328514044379266862004953478227925421141,
+                             -0.65486073394528506405692507247051100153382876839305,
+                             -0.95949297361449738989036805707015078470561785768624 };
+        return t[k];
+    }
+    static FA_DEV double s(int k) {
+        const double t[] = { 0.0, 0.54064081745559758210763595432149119841854573665417,
+                             0.90963199535451837141171538308025438115339826461594,
+                             0.98982144188093273237609203778476468501456787301956,
+                             0.75574957435425828377403584396999779705476123571770,
+                             0.28173255684142969771141791534956274523286476786253 };
+        return t[k];
+    }
+};
+template <> struct OddTrig<13> {
+    static FA_DEV double c(int k) {
+        const double t[] = { 1.0, 0.88545602565320989589618721428105947001195879239484,
+                             0.56806474673115580251180755912752337437587109759741,
+                             0.12053668025532305334906768745253665704210710478091,
+                             -0.35460488704253562596963789260002222810827551844950,
+                             -0.74851074817110109863463059970135073301528603526167,
+                             -0.97094181742605202715698227629378922724986131856198 };
+        return t[k];
+    }
+    static FA_DEV double s(int k) {
+        const double t[] = { 0.0, 0.46472317204376854565630555298924221625422258894859,
+                             0.82298386589365639457961001233239279374986520735366,
+                             0.99270887409805399280075894973008888491603537321479,
+                             0.93501624268541482343905466707503480354517331332141,
+                             0.66312265824079520237678549965245427733855323887033,
+                             0.23931566428755776714875372626641424363111980449113 };
+        return t[k];
+    }
+};
+
+template <int R> struct BflyOdd {
+    static FA_DEV void run(cplx *x) {
+        constexpr int H = (R - 1) / 2;
+        cplx a[H + 1], b[H + 1];
+        cplx x0 = x[0];
+        cplx sum = x0;
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            a[j] = c_add(x[j], x[R - j]);
+            b[j] = c_sub(x[j], x[R - j]);
+            sum = c_add(sum, a[j]);
+        }
+        x[0] = sum;
+#pragma unroll
+        for (int q = 1; q <= H; ++q) {
+            double ur = x0.x, ui = x0.y, vr = 0.0, vi = 0.0;
+#pragma unroll
+            for (int j = 1; j <= H; ++j) {
+                int m = (j * q) % R;           /* compile-time after unrolling */
+                double cs = OddTrig<R>::c(m <= H ? m : R - m);
+                double sn = OddTrig<R>::s(m <= H ? m : R - m);
+                if (m > H) sn = -sn;
+                ur += cs * a[j].x; ui += cs * a[j].y;
+                vr += sn * b[j].x; vi += sn * b[j].y;
+            }
+            /* X[q] = u - i v ; X[R-q] = u + i v */
+            x[q] = c_make(ur + vi, ui - vr);
+            x[R - q] = c_make(ur - vi, ui + vr);
+        }
+    }
+};
+
+template <> struct Bfly<3> : BflyOdd<3> {};
+template <> struct Bfly<5> : BflyOdd<5> {};
+template <> struct Bfly<7> : BflyOdd<7> {};
+template <> struct Bfly<11> : BflyOdd<11> {};
+template <> struct Bfly<13> : BflyOdd<13> {};
+
+#endif /* FA_BUTTERFLIES_H */

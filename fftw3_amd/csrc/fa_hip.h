@@ -1,0 +1,37 @@
+/*
+ * fa_hip.h -- the thin C ABI between the C host planner (api.c / planner.c)
+ * and the HIP translation unit (kernels.hip).  Plain C types only.
+ */
+#ifndef FA_HIP_H
+#define FA_HIP_H
+
+#include <stddef.h>
+#include "fftw3_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int   fa_hip_device_count(void);
+void *fa_hip_malloc(size_t nbytes);
+void  fa_hip_free(void *p);
+void *fa_hip_host_malloc(size_t nbytes);  /* pinned; NULL when no device runtime */
+int   fa_hip_host_free(void *p);          /* 0 when p was not a pinned allocation */
+/* 1: device-accessible pointer (hipMalloc / managed / registered), 0: plain host */
+int   fa_hip_is_device_ptr(const void *p);
+void  fa_hip_memcpy_h2d(void *dst, const void *src, size_t nbytes, void *stream);
+void  fa_hip_memcpy_d2h(void *dst, const void *src, size_t nbytes, void *stream);
+void  fa_hip_memset(void *dst, int v, size_t nbytes, void *stream);
+void  fa_hip_stream_sync(void *stream);
+
+/* Launch one step.  bufs[i] is the device base pointer of buffer id i, tables[i]
+   the device pointer of table id i.  (chunk_start, chunk_n) select the slice
+   of the batch loop when desc->batch_dim >= 0.  Returns 0 on success. */
+int fa_hip_launch_step(const fftw_amd_step_desc *desc, double *const *bufs,
+                       void *const *tables, long long chunk_start, long long chunk_n,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

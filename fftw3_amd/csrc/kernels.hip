@@ -1,0 +1,698 @@
+/*
+ * kernels.hip -- hand-written HIP kernels for gfx950 (MI355X) and their
+ * launchers.  No rocFFT/hipFFT, no MFMA: batched FFT passes are HBM-bound
+ * vector-FMA work.
+ *
+ * What each kernel replaces in the reference (fftw/fftw_api.c, "A.c"):
+ *   pass_generic_kernel  <- the leaf executors and the Cooley-Tukey twiddle
+ *       step: vrank_geq1_apply A.c:4627, ct_apply_dit A.c:2078, direct_apply
+ *       A.c:3182, dftw_direct_apply A.c:2315, dftw_generic A.c:2730-2903 and
+ *       the large-radix dftw_genericbuf A.c:2905-3109 (two-level twiddles,
+ *       A.c:18920-18941), with the n1/t1 codelets replaced by butterflies.h.
+ *   copy_kernel          <- cpy2d_pair copies A.c:16412-16452, Bluestein
+ *       chirp products A.c:1642-1688, Rader gather/scatter A.c:4187-4261.
+ *   r2c_post / c2r_pre   <- ct_hc2c_direct_apply A.c:5831-5845 with the
+ *       hc2cfdft / hc2cbdft codelets, plus the DC/Nyquist zeroing A.c:7155.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define FA_DEV __device__ __forceinline__
+#include "butterflies.h"
+#include "fa_hip.h"
+
+typedef long long i64;
+
+#define FA_CHECK(call)                                                              \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            fprintf(stderr, "fftw3_amd: HIP error %s at %s:%d (%s)\n",             \
+                    hipGetErrorString(e_), __FILE__, __LINE__, #call);              \
+            abort();                                                                \
+        }                                                                           \
+    } while (0)
+
+/* ------------------------------------------------------------------------ */
+/* element access helpers                                                    */
+/* ------------------------------------------------------------------------ */
+
+template <bool VEC>
+FA_DEV cplx load_elem(const double *p, i64 a, i64 im, int flags) {
+    cplx v;
+    if (VEC) {
+        v = *reinterpret_cast<const cplx *>(p + a);
+    } else {
+        v.x = p[a];
+        v.y = (flags & FFTW_AMD_F_REAL_IN) ? 0.0 : p[a + im];
+    }
+    if (flags & FFTW_AMD_F_SWAP_IN) { double t = v.x; v.x = v.y; v.y = t; }
+    return v;
+}
+
+template <bool VEC>
+FA_DEV void store_elem(double *p, i64 a, i64 im, int flags, cplx v) {
+    if (flags & FFTW_AMD_F_CONJ_OUT) v.y = -v.y;
+    if (flags & FFTW_AMD_F_SWAP_OUT) { double t = v.x; v.x = v.y; v.y = t; }
+    if (VEC) {
+        *reinterpret_cast<cplx *>(p + a) = v;
+    } else {
+        p[a] = v.x;
+        if (!(flags & FFTW_AMD_F_REAL_OUT)) p[a + im] = v.y;
+    }
+}
+
+/* w^m from the two-level table: (cos, sin)(2 pi m / n) */
+FA_DEV cplx tw2(const cplx *lo, const cplx *hi, int shift, i64 m) {
+    cplx a = lo[m & ((1LL << shift) - 1)];
+    cplx b = hi[m >> shift];
+    return c_mul(a, b);
+}
+
+/* ------------------------------------------------------------------------ */
+/* generic LDS pass kernel (runtime radices)                                 */
+/* ------------------------------------------------------------------------ */
+
+struct PassArgs {
+    const double *src;
+    double *dst;
+    i64 src_im, dst_im;
+    i64 is_l, os_l;
+    i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS], dtw[FFTW_AMD_MAX_DIMS];
+    const cplx *wL;
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    i64 tw_n;
+    i64 ntiles;
+    int tw_shift;
+    int L, nrad;
+    int rad[FFTW_AMD_MAX_RADICES];
+    int ndims, T, ld, flags;
+    int in_t_fast, out_t_fast;
+};
+
+template <int R>
+FA_DEV void stockham_stage(const cplx *A, cplx *B, const cplx *wL, int L, int ld, int Tcur,
+                           int Ns, int tid, int nth) {
+    const int m = L / R;
+    const int nb = m * Tcur;
+    const int twstep = L / (Ns * R);
+    for (int b = tid; b < nb; b += nth) {
+        int j = b / Tcur, t = b - j * Tcur;
+        int k = j % Ns;
+        cplx x[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) x[i] = A[(j + i * m) * ld + t];
+        if (Ns > 1) {
+#pragma unroll
+            for (int i = 1; i < R; ++i) x[i] = c_mulc(x[i], wL[i * k * twstep]);
+        }
+        Bfly<R>::run(x);
+        int o = (j - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) B[(o + q * Ns) * ld + t] = x[q];
+    }
+}
+
+/* any prime radix p: O(p^2) DFT straight out of LDS (reference generic_apply,
+   A.c:3428-3448, plays this role for primes without a codelet) */
+FA_DEV void stockham_stage_prime(const cplx *A, cplx *B, const cplx *wL, int L, int ld, int Tcur,
+                                 int Ns, int p, int tid, int nth) {
+    const int m = L / p;
+    const int nb = m * Tcur;
+    const int twstep = L / (Ns * p);
+    const int pstep = L / p;
+    for (int b = tid; b < nb; b += nth) {
+        int j = b / Tcur, t = b - j * Tcur;
+        int k = j % Ns;
+        int o = (j - k) * p + k;
+        for (int q = 0; q < p; ++q) {
+            cplx acc = c_make(0.0, 0.0);
+            int iq = 0;
+            for (int i = 0; i < p; ++i) {
+                cplx xi = A[(j + i * m) * ld + t];
+                if (Ns > 1) xi = c_mulc(xi, wL[i * k * twstep]);
+                xi = c_mulc(xi, wL[iq * pstep]);
+                acc = c_add(acc, xi);
+                iq += q;
+                if (iq >= p) iq -= p;
+            }
+            B[(o + q * Ns) * ld + t] = acc;
+        }
+    }
+}
+
+template <bool VIN, bool VOUT>
+__global__ void __launch_bounds__(256)
+pass_generic_kernel(const PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fa_lds_raw[];
+    cplx *A = reinterpret_cast<cplx *>(fa_lds_raw);
+    cplx *B = A + (size_t)a.L * a.ld;
+
+    const int tid = threadIdx.x, nth = blockDim.x;
+    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
+    i64 tile = blk % a.ntiles;
+    i64 rest = blk / a.ntiles;
+    i64 soff = 0, doff = 0, twb = 0;
+    for (int d = 1; d < a.ndims; ++d) {
+        i64 idx = rest % a.dn[d];
+        rest /= a.dn[d];
+        soff += idx * a.dis[d];
+        doff += idx * a.dos[d];
+        twb += idx * a.dtw[d];
+    }
+    const i64 t0 = tile * a.T;
+    const int Tcur = (int)((a.dn[0] - t0 < a.T) ? (a.dn[0] - t0) : a.T);
+    const int L = a.L, ld = a.ld;
+    const int total = L * Tcur;
+
+    /* ---- load tile into LDS, coalesced along whichever index is contiguous */
+    for (int e = tid; e < total; e += nth) {
+        int l, t;
+        if (a.in_t_fast) { l = e / Tcur; t = e - l * Tcur; }
+        else             { t = e / L;    l = e - t * L; }
+        i64 addr = soff + (i64)l * a.is_l + (t0 + t) * a.dis[0];
+        A[l * ld + t] = load_elem<VIN>(a.src, addr, a.src_im, a.flags);
+    }
+    __syncthreads();
+
+    /* ---- Stockham autosort stages, ping-pong between the two LDS images */
+    int Ns = 1;
+    for (int s = 0; s < a.nrad; ++s) {
+        const int r = a.rad[s];
+        switch (r) {
+        case 2:  stockham_stage<2>(A, B, a.wL, L, ld, Tcur, Ns, tid, nth); break;
+        case 3:  stockham_stage<3>(A, B, a.wL, L, ld, Tcur, Ns, tid, nth); break;
+        case 4:  stockham_stage<4>(A, B, a.wL, L, ld, Tcur, Ns, tid, nth); break;
+        case 5:  stockham_stage<5>(A, B, a.wL, L, ld, Tcur, Ns, tid, nth); break;
+        case 7:  stockham_stage<7>(A, B, a.wL, L, ld, Tcur, Ns, tid, nth); break;
+        case 8:  stockham_stage<8>(A, B, a.wL, L, ld, Tcur, Ns, tid, nth); break;
+        case 11: stockham_stage<11>(A, B, a.wL, L, ld, Tcur, Ns, tid, nth); break;
+        case 13: stockham_stage<13>(A, B, a.wL, L, ld, Tcur, Ns, tid, nth); break;
+        case 16: stockham_stage<16>(A, B, a.wL, L, ld, Tcur, Ns, tid, nth); break;
+        default: stockham_stage_prime(A, B, a.wL, L, ld, Tcur, Ns, r, tid, nth); break;
+        }
+        Ns *= r;
+        cplx *tmp = A; A = B; B = tmp;
+        __syncthreads();
+    }
+
+    /* ---- inter-pass twiddle (conj: forward) and store */
+    for (int e = tid; e < total; e += nth) {
+        int l, t;
+        if (a.out_t_fast) { l = e / Tcur; t = e - l * Tcur; }
+        else              { t = e / L;    l = e - t * L; }
+        cplx v = A[l * ld + t];
+        if (a.tw_n) {
+            i64 m = (i64)l * (twb + (t0 + t) * a.dtw[0]);
+            v = c_mulc(v, tw2(a.tw_lo, a.tw_hi, a.tw_shift, m));
+        }
+        i64 addr = doff + (i64)l * a.os_l + (t0 + t) * a.dos[0];
+        store_elem<VOUT>(a.dst, addr, a.dst_im, a.flags, v);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* strided copy / pad / multiply / permute                                   */
+/* ------------------------------------------------------------------------ */
+
+struct CopyArgs {
+    const double *src;
+    double *dst;
+    i64 src_im, dst_im;
+    i64 is_k, os_k;
+    i64 K, Kvalid, total;
+    i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
+    const cplx *tab;
+    const i64 *perm;
+    int ndims, flags;
+};
+
+__global__ void __launch_bounds__(256) copy_kernel(const CopyArgs a) {
+    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; gid < a.total; gid += stride) {
+        i64 k = gid % a.K;
+        i64 rest = gid / a.K;
+        i64 soff = 0, doff = 0;
+        for (int d = 0; d < a.ndims; ++d) {
+            i64 idx = rest % a.dn[d];
+            rest /= a.dn[d];
+            soff += idx * a.dis[d];
+            doff += idx * a.dos[d];
+        }
+        cplx v = c_make(0.0, 0.0);
+        if (k < a.Kvalid) {
+            i64 ks = (a.flags & FFTW_AMD_F_PERM_SRC) ? a.perm[k] : k;
+            v = load_elem<false>(a.src, soff + ks * a.is_k, a.src_im, a.flags);
+        }
+        if (a.flags & FFTW_AMD_F_MUL_TABLE) v = c_mul(v, a.tab[k]);
+        if (a.flags & FFTW_AMD_F_MUL_CONJ) v = c_mulc(v, a.tab[k]);
+        i64 kd = (a.flags & FFTW_AMD_F_PERM_DST) ? a.perm[k] : k;
+        store_elem<false>(a.dst, doff + kd * a.os_k, a.dst_im, a.flags, v);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* r2c untangle / c2r tangle                                                 */
+/* ------------------------------------------------------------------------ */
+
+struct RealArgs {
+    const double *src;
+    double *dst;
+    i64 src_im, dst_im;
+    i64 is_k, os_k;
+    i64 h;       /* n / 2 */
+    i64 npair;   /* h / 2 + 1 */
+    i64 total;
+    i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    int tw_shift;
+    int ndims, flags;
+};
+
+/* Y[k] = E + w^k O, Y[h-k] = conj(E - w^k O), E = (Z[k] + conj Z[h-k]) / 2,
+   O = -i (Z[k] - conj Z[h-k]) / 2   (the 1/2 is the
+   KP500000000 of reference rdft_scalar/r2cf/hc2cfdft_4.c:137) */
+__global__ void __launch_bounds__(256) r2c_post_kernel(const RealArgs a) {
+    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; gid < a.total; gid += stride) {
+        i64 k = gid % a.npair;
+        i64 rest = gid / a.npair;
+        i64 soff = 0, doff = 0;
+        for (int d = 0; d < a.ndims; ++d) {
+            i64 idx = rest % a.dn[d];
+            rest /= a.dn[d];
+            soff += idx * a.dis[d];
+            doff += idx * a.dos[d];
+        }
+        i64 km = a.h - k;
+        cplx zk = load_elem<false>(a.src, soff + k * a.is_k, a.src_im, 0);
+        cplx zm = load_elem<false>(a.src, soff + (km == a.h ? 0 : km) * a.is_k, a.src_im, 0);
+        cplx E = c_make(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        cplx D = c_make(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
+        cplx O = c_mni(D);
+        cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k);
+        cplx P = c_mulc(O, w);
+        cplx yk = c_add(E, P);
+        cplx ym = c_sub(E, P);
+        ym.y = -ym.y;
+        if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+        store_elem<false>(a.dst, doff + k * a.os_k, a.dst_im, a.flags, yk);
+        if (km != k) store_elem<false>(a.dst, doff + km * a.os_k, a.dst_im, a.flags, ym);
+    }
+}
+
+/* Z'[k] = E' + i O', Z'[h-k] = conj(E' - i O'), E' = Y[k] + conj Y[h-k],
+   O' = (Y[k] - conj Y[h-k]) w^-k  (transpose of the above; reference
+   hc2cbdft codelets, no 1/2) */
+__global__ void __launch_bounds__(256) c2r_pre_kernel(const RealArgs a) {
+    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; gid < a.total; gid += stride) {
+        i64 k = gid % a.npair;
+        i64 rest = gid / a.npair;
+        i64 soff = 0, doff = 0;
+        for (int d = 0; d < a.ndims; ++d) {
+            i64 idx = rest % a.dn[d];
+            rest /= a.dn[d];
+            soff += idx * a.dis[d];
+            doff += idx * a.dos[d];
+        }
+        i64 km = a.h - k;
+        cplx yk = load_elem<false>(a.src, soff + k * a.is_k, a.src_im, 0);
+        cplx ym = load_elem<false>(a.src, soff + km * a.is_k, a.src_im, 0);
+        if (k == 0) { yk.y = 0.0; ym.y = 0.0; }   /* Im Y[0], Im Y[n/2] are ignored */
+        cplx E = c_make(yk.x + ym.x, yk.y - ym.y);
+        cplx D = c_make(yk.x - ym.x, yk.y + ym.y);
+        cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k);
+        cplx O = c_mul(D, w);
+        cplx iO = c_mpi(O);
+        cplx zk = c_add(E, iO);
+        cplx zm = c_sub(E, iO);
+        zm.y = -zm.y;
+        store_elem<false>(a.dst, doff + k * a.os_k, a.dst_im, a.flags, zk);
+        if (km != k && km != a.h)
+            store_elem<false>(a.dst, doff + km * a.os_k, a.dst_im, a.flags, zm);
+    }
+}
+
+/* Rader: P[k] = A[k] * Omega[k]; P[0] += x0; Y[0] = x0 + A[0]
+   (reference rader_apply A.c:4218-4240) */
+struct RaderArgs {
+    double *work;        /* [vec][p-1] complex, contiguous */
+    const double *x0;    /* [vec] complex */
+    double *dst;         /* where Y[0] goes */
+    i64 dst_im;
+    i64 pm1, nvec, total;
+    i64 dn[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
+    const cplx *omega;
+    int ndims, flags;
+};
+
+__global__ void __launch_bounds__(256) rader_mul_kernel(const RaderArgs a) {
+    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; gid < a.total; gid += stride) {
+        i64 k = gid % a.pm1;
+        i64 v = gid / a.pm1;
+        cplx *w = reinterpret_cast<cplx *>(a.work) + v * a.pm1;
+        cplx A = w[k];
+        cplx P = c_mul(A, a.omega[k]);
+        if (k == 0) {
+            cplx x0 = reinterpret_cast<const cplx *>(a.x0)[v];
+            P = c_add(P, x0);
+            i64 rest = v, doff = 0;
+            for (int d = 0; d < a.ndims; ++d) {
+                i64 idx = rest % a.dn[d];
+                rest /= a.dn[d];
+                doff += idx * a.dos[d];
+            }
+            store_elem<false>(a.dst, doff, a.dst_im, a.flags, c_add(x0, A));
+        }
+        w[k] = P;
+    }
+}
+
+/* half spectrum Y[0..n/2] -> full Hermitian spectrum F[0..n-1] (odd-n c2r) */
+__global__ void __launch_bounds__(256) herm_expand_kernel(const CopyArgs a) {
+    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; gid < a.total; gid += stride) {
+        i64 k = gid % a.K;
+        i64 rest = gid / a.K;
+        i64 soff = 0, doff = 0;
+        for (int d = 0; d < a.ndims; ++d) {
+            i64 idx = rest % a.dn[d];
+            rest /= a.dn[d];
+            soff += idx * a.dis[d];
+            doff += idx * a.dos[d];
+        }
+        i64 half = a.K / 2;
+        i64 ks = (k <= half) ? k : a.K - k;
+        cplx v = load_elem<false>(a.src, soff + ks * a.is_k, a.src_im, 0);
+        if (k > half) v.y = -v.y;
+        if (k == 0 || (2 * k == a.K)) v.y = 0.0;
+        store_elem<false>(a.dst, doff + k * a.os_k, a.dst_im, a.flags, v);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* host side                                                                 */
+/* ------------------------------------------------------------------------ */
+
+static int g_dev_count = -1;
+
+extern "C" int fa_hip_device_count(void) {
+    if (g_dev_count < 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+        g_dev_count = n;
+    }
+    return g_dev_count;
+}
+
+extern "C" void *fa_hip_malloc(size_t nbytes) {
+    void *p = NULL;
+    if (nbytes == 0) nbytes = 16;
+    FA_CHECK(hipMalloc(&p, nbytes));
+    return p;
+}
+
+extern "C" void fa_hip_free(void *p) {
+    if (p) FA_CHECK(hipFree(p));
+}
+
+extern "C" void *fa_hip_host_malloc(size_t nbytes) {
+    if (fa_hip_device_count() <= 0) return NULL;
+    void *p = NULL;
+    if (hipHostMalloc(&p, nbytes ? nbytes : 16, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return NULL;
+    }
+    return p;
+}
+
+extern "C" int fa_hip_host_free(void *p) {
+    if (fa_hip_device_count() <= 0) return 0;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (attr.type == hipMemoryTypeHost) { FA_CHECK(hipHostFree(p)); return 1; }
+    return 0;
+}
+
+extern "C" int fa_hip_is_device_ptr(const void *p) {
+    if (!p || fa_hip_device_count() <= 0) return 0;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+extern "C" void fa_hip_memcpy_h2d(void *dst, const void *src, size_t n, void *stream) {
+    FA_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, (hipStream_t)stream));
+}
+extern "C" void fa_hip_memcpy_d2h(void *dst, const void *src, size_t n, void *stream) {
+    FA_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+}
+extern "C" void fa_hip_memset(void *dst, int v, size_t n, void *stream) {
+    FA_CHECK(hipMemsetAsync(dst, v, n, (hipStream_t)stream));
+}
+extern "C" void fa_hip_stream_sync(void *stream) {
+    FA_CHECK(hipStreamSynchronize((hipStream_t)stream));
+}
+
+static inline i64 iabs64(i64 v) { return v < 0 ? -v : v; }
+
+static void grid_for(i64 total, dim3 *grid) {
+    i64 blocks = (total + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 32) blocks = 256 * 32;   /* grid-stride beyond that */
+    *grid = dim3((unsigned)blocks, 1, 1);
+}
+
+/* offsets applied for the current batch chunk: user buffers advance, scratch
+   buffers are reused per chunk */
+static inline i64 chunk_adv(int buf, i64 chunk_start, i64 stride) {
+    return (buf < 2) ? chunk_start * stride : 0;
+}
+
+static int g_lds_attr_done = 0;
+
+template <bool VIN, bool VOUT>
+static void launch_pass_variant(const PassArgs &pa, dim3 grid, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((pass_generic_kernel<VIN, VOUT>), grid, dim3(256), lds, st, pa);
+}
+
+static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                       i64 cs, i64 cn, hipStream_t st) {
+    PassArgs pa;
+    int bd = d->batch_dim;
+    i64 sbase = d->src_base, dbase = d->dst_base;
+    for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+        pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+        pa.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+        pa.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+        pa.dtw[i] = (i < d->ndims) ? d->dim_tw[i] : 0;
+    }
+    if (bd >= 0) {
+        sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+        dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+        pa.dn[bd] = cn;
+    }
+    pa.src = bufs[d->src_buf] + sbase;
+    pa.dst = bufs[d->dst_buf] + dbase;
+    pa.src_im = d->src_im;
+    pa.dst_im = d->dst_im;
+    pa.is_l = d->is_l;
+    pa.os_l = d->os_l;
+    pa.wL = (d->table >= 0) ? (const cplx *)tables[d->table] : NULL;
+    pa.tw_n = d->tw_n;
+    pa.tw_shift = d->tw_shift;
+    pa.tw_lo = d->tw_n ? (const cplx *)tables[d->tw_lo] : NULL;
+    pa.tw_hi = d->tw_n ? (const cplx *)tables[d->tw_hi] : NULL;
+    pa.L = d->L;
+    pa.nrad = d->nradices;
+    for (int i = 0; i < FFTW_AMD_MAX_RADICES; ++i) pa.rad[i] = (i < d->nradices) ? d->radices[i] : 1;
+    pa.ndims = d->ndims;
+    pa.T = d->tile;
+    pa.ld = (d->tile > 1) ? (d->tile | 1) : 1;
+    pa.flags = d->flags;
+    pa.ntiles = (pa.dn[0] + pa.T - 1) / pa.T;
+    /* a stride-0 dim cannot be the coalescing index */
+    pa.in_t_fast = (pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l)) || pa.L == 1;
+    pa.out_t_fast = (pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l)) || pa.L == 1;
+
+    i64 nblocks = pa.ntiles;
+    for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
+    if (nblocks <= 0) return 0;
+    dim3 grid;
+    if (nblocks <= 0x7fffffffLL) grid = dim3((unsigned)nblocks, 1, 1);
+    else {
+        /* split over y; the kernel recombines.  nblocks must factor: use 65535-ish rows */
+        unsigned gy = (unsigned)((nblocks + 0x3fffffffLL) / 0x40000000LL);
+        while (nblocks % gy) ++gy;
+        grid = dim3((unsigned)(nblocks / gy), gy, 1);
+    }
+    size_t lds = (size_t)2 * pa.L * pa.ld * sizeof(cplx);
+    if (lds > 160 * 1024) {
+        fprintf(stderr, "fftw3_amd: internal error: pass tile needs %zu B of LDS\n", lds);
+        return -1;
+    }
+    if (!g_lds_attr_done) {
+        FA_CHECK(hipFuncSetAttribute((const void *)pass_generic_kernel<false, false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass_generic_kernel<true, false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass_generic_kernel<false, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass_generic_kernel<true, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_lds_attr_done = 1;
+    }
+    /* 16-byte vector access when the element is an aligned interleaved pair */
+    bool vin = d->src_im == 1 && !(d->flags & FFTW_AMD_F_REAL_IN) &&
+               ((uintptr_t)pa.src % 16 == 0) && (pa.is_l % 2 == 0);
+    bool vout = d->dst_im == 1 && !(d->flags & FFTW_AMD_F_REAL_OUT) &&
+                ((uintptr_t)pa.dst % 16 == 0) && (pa.os_l % 2 == 0);
+    for (int i = 0; i < d->ndims; ++i) {
+        if (pa.dis[i] % 2) vin = false;
+        if (pa.dos[i] % 2) vout = false;
+    }
+    if (vin && vout) launch_pass_variant<true, true>(pa, grid, lds, st);
+    else if (vin) launch_pass_variant<true, false>(pa, grid, lds, st);
+    else if (vout) launch_pass_variant<false, true>(pa, grid, lds, st);
+    else launch_pass_variant<false, false>(pa, grid, lds, st);
+    return 0;
+}
+
+static void fill_copy_args(CopyArgs *ca, const fftw_amd_step_desc *d, double *const *bufs,
+                           void *const *tables, i64 cs, i64 cn) {
+    int bd = d->batch_dim;
+    i64 sbase = d->src_base, dbase = d->dst_base;
+    for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+        ca->dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+        ca->dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+        ca->dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+    }
+    if (bd >= 0) {
+        sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+        dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+        ca->dn[bd] = cn;
+    }
+    ca->src = bufs[d->src_buf] + sbase;
+    ca->dst = bufs[d->dst_buf] + dbase;
+    ca->src_im = d->src_im;
+    ca->dst_im = d->dst_im;
+    ca->is_k = d->is_l;
+    ca->os_k = d->os_l;
+    ca->K = d->aux_n;
+    ca->Kvalid = d->aux_valid;
+    ca->ndims = d->ndims;
+    ca->flags = d->flags;
+    ca->tab = (d->table >= 0) ? (const cplx *)tables[d->table] : NULL;
+    ca->perm = (d->table2 >= 0) ? (const i64 *)tables[d->table2] : NULL;
+    i64 total = ca->K;
+    for (int i = 0; i < d->ndims; ++i) total *= ca->dn[i];
+    ca->total = total;
+}
+
+extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bufs,
+                                  void *const *tables, long long cs, long long cn,
+                                  void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (d->kind) {
+    case FFTW_AMD_STEP_PASS:
+        return launch_pass(d, bufs, tables, cs, cn, st);
+    case FFTW_AMD_STEP_COPY:
+    case FFTW_AMD_STEP_HERM_EXPAND: {
+        CopyArgs ca;
+        fill_copy_args(&ca, d, bufs, tables, cs, cn);
+        if (ca.total <= 0) return 0;
+        dim3 grid;
+        grid_for(ca.total, &grid);
+        if (d->kind == FFTW_AMD_STEP_COPY)
+            hipLaunchKernelGGL(copy_kernel, grid, dim3(256), 0, st, ca);
+        else
+            hipLaunchKernelGGL(herm_expand_kernel, grid, dim3(256), 0, st, ca);
+        return 0;
+    }
+    case FFTW_AMD_STEP_R2C_POST:
+    case FFTW_AMD_STEP_C2R_PRE: {
+        RealArgs ra;
+        int bd = d->batch_dim;
+        i64 sbase = d->src_base, dbase = d->dst_base;
+        for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+            ra.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+            ra.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+            ra.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+        }
+        if (bd >= 0) {
+            sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+            dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+            ra.dn[bd] = cn;
+        }
+        ra.src = bufs[d->src_buf] + sbase;
+        ra.dst = bufs[d->dst_buf] + dbase;
+        ra.src_im = d->src_im;
+        ra.dst_im = d->dst_im;
+        ra.is_k = d->is_l;
+        ra.os_k = d->os_l;
+        ra.h = d->aux_n / 2;
+        ra.npair = ra.h / 2 + 1;
+        ra.tw_lo = (const cplx *)tables[d->tw_lo];
+        ra.tw_hi = (const cplx *)tables[d->tw_hi];
+        ra.tw_shift = d->tw_shift;
+        ra.ndims = d->ndims;
+        ra.flags = d->flags;
+        i64 total = ra.npair;
+        for (int i = 0; i < d->ndims; ++i) total *= ra.dn[i];
+        ra.total = total;
+        if (total <= 0) return 0;
+        dim3 grid;
+        grid_for(total, &grid);
+        if (d->kind == FFTW_AMD_STEP_R2C_POST)
+            hipLaunchKernelGGL(r2c_post_kernel, grid, dim3(256), 0, st, ra);
+        else
+            hipLaunchKernelGGL(c2r_pre_kernel, grid, dim3(256), 0, st, ra);
+        return 0;
+    }
+    case FFTW_AMD_STEP_RADER_MUL: {
+        RaderArgs ra;
+        int bd = d->batch_dim;
+        i64 dbase = d->dst_base;
+        i64 nvec = 1;
+        for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+            ra.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+            ra.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+        }
+        if (bd >= 0) {
+            dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+            ra.dn[bd] = cn;
+        }
+        for (int i = 0; i < d->ndims; ++i) nvec *= ra.dn[i];
+        ra.work = bufs[d->src_buf] + d->src_base;
+        ra.x0 = bufs[d->aux_buf] + d->aux_base;
+        ra.dst = bufs[d->dst_buf] + dbase;
+        ra.dst_im = d->dst_im;
+        ra.pm1 = d->aux_n;
+        ra.nvec = nvec;
+        ra.total = nvec * ra.pm1;
+        ra.omega = (const cplx *)tables[d->table];
+        ra.ndims = d->ndims;
+        ra.flags = d->flags;
+        if (ra.total <= 0) return 0;
+        dim3 grid;
+        grid_for(ra.total, &grid);
+        hipLaunchKernelGGL(rader_mul_kernel, grid, dim3(256), 0, st, ra);
+        return 0;
+    }
+    default:
+        fprintf(stderr, "fftw3_amd: unknown step kind %d\n", d->kind);
+        return -1;
+    }
+}

@@ -1,0 +1,1182 @@
+/*
+ * planner.c -- the static GPU planner: turns a DFT problem (dims + strides)
+ * into a short list of kernel launches ("steps").
+ *
+ * It replaces the reference's search-based planner (ifftw_mkplan,
+ * fftw/fftw_api.c:15300-15426) and restates the *structure* of the solvers it
+ * would have picked:
+ *   - Cooley-Tukey n = L1*L2*...  (ct_mkplan A.c:2183-2202)  -> fa_emit_ct
+ *   - vector / rank loops (vrank_geq1 A.c:4627, rank_geq2 A.c:4435) -> loop
+ *     dims carried by every step and executed by the kernel grid
+ *   - Rader (A.c:4187-4261) and Bluestein (A.c:1642-1688) for sizes with a
+ *     prime factor the LDS kernel has no stage for
+ *   - rdft2 via half-length complex DFT + untangle (ct_hc2c A.c:5579-5590)
+ * A CPU cost model is meaningless on the GPU, so there is no search: the
+ * decomposition is a function of n and of which index is contiguous.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fa_plan.h"
+#include "fa_hip.h"
+
+typedef struct fftw_plan_s plan;
+
+static size_t g_chunk_bytes = (size_t)64 << 20;
+static i64 g_lmax_multi = 1024;
+
+void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : ((size_t)64 << 20); }
+
+static i64 iabs(i64 v) { return v < 0 ? -v : v; }
+
+/* ------------------------------------------------------------------ plan */
+
+plan *fa_plan_new(void) {
+    plan *p = (plan *)calloc(1, sizeof(plan));
+    const char *e;
+    if (!p) return NULL;
+    p->nbufs = 2;
+    p->in_im = p->out_im = 1;
+    e = getenv("FFTW_AMD_CHUNK_BYTES");
+    if (e && atoll(e) > 0) g_chunk_bytes = (size_t)atoll(e);
+    e = getenv("FFTW_AMD_LMAX_MULTI");
+    if (e && atoll(e) >= 16) g_lmax_multi = atoll(e);
+    return p;
+}
+
+static void plan_reset_build(plan *p) {
+    int i;
+    free(p->steps);
+    p->steps = NULL;
+    p->nsteps = p->cap_steps = 0;
+    for (i = 0; i < p->ntabs; ++i) free(p->tabs[i].host);
+    memset(p->tabs, 0, sizeof(p->tabs));
+    p->ntabs = 0;
+    p->nbufs = 2;
+    memset(p->buf_reals, 0, sizeof(p->buf_reals));
+    memset(p->buf_busy, 0, sizeof(p->buf_busy));
+    p->failed = 0;
+    p->est_flops = 0;
+}
+
+void fa_plan_free(plan *p) {
+    int i;
+    if (!p) return;
+    if (p->dev_ready || p->stage_in || p->stage_out) {
+        fa_hip_stream_sync(p->stream);
+        for (i = 0; i < p->ntabs; ++i) fa_hip_free(p->tabs[i].dev);
+        for (i = 2; i < p->nbufs; ++i) fa_hip_free(p->dbuf[i]);
+        fa_hip_free(p->stage_in);
+        fa_hip_free(p->stage_out);
+    }
+    for (i = 0; i < p->ntabs; ++i) free(p->tabs[i].host);
+    free(p->steps);
+    free(p);
+}
+
+/* ---------------------------------------------------------------- tables */
+
+static int tab_find(plan *p, int kind, i64 n, i64 aux) {
+    int i;
+    for (i = 0; i < p->ntabs; ++i)
+        if (p->tabs[i].kind == kind && p->tabs[i].n == n && p->tabs[i].aux == aux) return i;
+    return -1;
+}
+
+static int tab_new(plan *p, int kind, i64 n, i64 aux, i64 len, size_t elem) {
+    fa_table *t;
+    if (p->ntabs >= FA_MAXTAB) { p->failed = 1; return 0; }
+    t = &p->tabs[p->ntabs];
+    t->kind = kind;
+    t->n = n;
+    t->aux = aux;
+    t->len = len;
+    t->src = -1;
+    t->host = len ? calloc((size_t)len, elem) : NULL;
+    t->dev = NULL;
+    return p->ntabs++;
+}
+
+static int tab_stage(plan *p, i64 L) {
+    int id = tab_find(p, FA_TAB_STAGE, L, 0);
+    double *h;
+    i64 m;
+    if (id >= 0) return id;
+    id = tab_new(p, FA_TAB_STAGE, L, 0, L, 2 * sizeof(double));
+    h = (double *)p->tabs[id].host;
+    for (m = 0; m < L; ++m) fa_cexp(m, L, h + 2 * m);
+    return id;
+}
+
+/* w^m = lo[m & (2^s - 1)] * hi[m >> s], both factors exact table entries:
+   the reference's sqrt(n) scheme for large radix steps
+   (fftw/fftw_api.c:18989-19011, rotate A.c:18920-18941) */
+static void tab_tw2(plan *p, i64 n, int *lo, int *hi, int *shift) {
+    int s = 0, id;
+    i64 m, nlo, nhi;
+    double *h;
+    while (((i64)1 << (2 * s)) < n) ++s;
+    nlo = (i64)1 << s;
+    nhi = (n + nlo - 1) / nlo;
+    *shift = s;
+    id = tab_find(p, FA_TAB_TW_LO, n, s);
+    if (id < 0) {
+        id = tab_new(p, FA_TAB_TW_LO, n, s, nlo, 2 * sizeof(double));
+        h = (double *)p->tabs[id].host;
+        for (m = 0; m < nlo; ++m) fa_cexp(m, n, h + 2 * m);
+    }
+    *lo = id;
+    id = tab_find(p, FA_TAB_TW_HI, n, s);
+    if (id < 0) {
+        id = tab_new(p, FA_TAB_TW_HI, n, s, nhi, 2 * sizeof(double));
+        h = (double *)p->tabs[id].host;
+        for (m = 0; m < nhi; ++m) fa_cexp(m << s, n, h + 2 * m);
+    }
+    *hi = id;
+}
+
+/* Bluestein chirp w[k] = exp(+i pi k^2 / n), k^2 reduced mod 2n first
+   (reference bluestein_sequence, fftw/fftw_api.c:1598-1611) */
+static int tab_chirp(plan *p, i64 n, i64 nb) {
+    int id = tab_find(p, FA_TAB_CHIRP, n, nb);
+    double *h;
+    i64 k;
+    if (id >= 0) return id;
+    id = tab_new(p, FA_TAB_CHIRP, n, nb, nb, 2 * sizeof(double));
+    h = (double *)p->tabs[id].host;
+    for (k = 0; k < n; ++k) fa_cexp(fa_mulmod(k, k, 2 * n), 2 * n, h + 2 * k);
+    return id;
+}
+
+static int tab_dft_of(plan *p, int src, i64 n) {
+    int id = tab_find(p, FA_TAB_DFT_OF, n, src);
+    if (id >= 0) return id;
+    id = tab_new(p, FA_TAB_DFT_OF, n, src, n, 2 * sizeof(double));
+    free(p->tabs[id].host);
+    p->tabs[id].host = NULL;
+    p->tabs[id].src = src;
+    return id;
+}
+
+/* DFT_nb( w[0], w[1..n-1], 0.., w[n-1..1] ) / nb  (A.c:1624-1639) */
+static int tab_blue_kernel(plan *p, i64 n, i64 nb) {
+    int seq = tab_find(p, FA_TAB_BLUE_SEQ, n, nb);
+    if (seq < 0) {
+        double *h, w[2];
+        i64 k;
+        seq = tab_new(p, FA_TAB_BLUE_SEQ, n, nb, nb, 2 * sizeof(double));
+        h = (double *)p->tabs[seq].host;
+        for (k = 0; k < n; ++k) {
+            fa_cexp(fa_mulmod(k, k, 2 * n), 2 * n, w);
+            h[2 * k] = w[0] / (double)nb;
+            h[2 * k + 1] = w[1] / (double)nb;
+            if (k) {
+                h[2 * (nb - k)] = h[2 * k];
+                h[2 * (nb - k) + 1] = h[2 * k + 1];
+            }
+        }
+    }
+    return tab_dft_of(p, seq, nb);
+}
+
+/* perm[k] = g^k mod p (inverse = 0) or g^-k mod p (inverse = 1), k in [0, p-1) */
+static int tab_perm(plan *p, i64 pr, int inverse) {
+    int id = tab_find(p, FA_TAB_PERM, pr, inverse);
+    i64 *h, g, x, k;
+    if (id >= 0) return id;
+    id = tab_new(p, FA_TAB_PERM, pr, inverse, pr - 1, sizeof(i64));
+    h = (i64 *)p->tabs[id].host;
+    g = fa_find_generator(pr);
+    if (inverse) g = fa_power_mod(g, pr - 2, pr);
+    x = 1;
+    for (k = 0; k < pr - 1; ++k) {
+        h[k] = x;
+        x = fa_mulmod(x, g, pr);
+    }
+    return id;
+}
+
+/* Omega = DFT_{p-1}( exp(-2 pi i g^-j / p) / (p-1) )   (rader_mkomega A.c:4139-4167) */
+static int tab_rader_kernel(plan *p, i64 pr) {
+    int seq = tab_find(p, FA_TAB_RADER_SEQ, pr, 0);
+    if (seq < 0) {
+        int pi = tab_perm(p, pr, 1);
+        const i64 *perm = (const i64 *)p->tabs[pi].host;
+        double *h, w[2];
+        i64 j;
+        seq = tab_new(p, FA_TAB_RADER_SEQ, pr, 0, pr - 1, 2 * sizeof(double));
+        h = (double *)p->tabs[seq].host;
+        for (j = 0; j < pr - 1; ++j) {
+            fa_cexp(perm[j], pr, w);
+            h[2 * j] = w[0] / (double)(pr - 1);
+            h[2 * j + 1] = -w[1] / (double)(pr - 1);
+        }
+    }
+    return tab_dft_of(p, seq, pr - 1);
+}
+
+/* --------------------------------------------------------------- buffers */
+
+static int buf_acquire(plan *p, i64 reals) {
+    int i;
+    for (i = 2; i < p->nbufs; ++i)
+        if (!p->buf_busy[i]) {
+            p->buf_busy[i] = 1;
+            if (p->buf_reals[i] < reals) p->buf_reals[i] = reals;
+            return i;
+        }
+    if (p->nbufs >= FA_MAXBUF) { p->failed = 1; return 2; }
+    i = p->nbufs++;
+    p->buf_busy[i] = 1;
+    p->buf_reals[i] = reals;
+    return i;
+}
+
+static void buf_release(plan *p, int id) { p->buf_busy[id] = 0; }
+
+/* ----------------------------------------------------------------- steps */
+
+static fftw_amd_step_desc *new_step(plan *p, int kind) {
+    fftw_amd_step_desc *s;
+    if (p->nsteps == p->cap_steps) {
+        p->cap_steps = p->cap_steps ? 2 * p->cap_steps : 16;
+        p->steps = (fftw_amd_step_desc *)realloc(p->steps, sizeof(*s) * (size_t)p->cap_steps);
+    }
+    s = &p->steps[p->nsteps++];
+    memset(s, 0, sizeof(*s));
+    s->kind = kind;
+    s->table = s->table2 = -1;
+    s->tw_lo = s->tw_hi = -1;
+    s->batch_dim = -1;
+    s->aux_buf = -1;
+    s->tile = 1;
+    s->variant = FFTW_AMD_K_GENERIC;
+    return s;
+}
+
+typedef struct { i64 n, is, os, tw; int is_batch; } sdim;
+
+/* put dims into the step; returns -1 if they do not fit */
+static int step_set_dims(plan *p, fftw_amd_step_desc *s, const sdim *d, int nd, int tile_idx) {
+    int i, k = 0;
+    if (tile_idx >= 0) {
+        s->dim_n[0] = d[tile_idx].n; s->dim_is[0] = d[tile_idx].is;
+        s->dim_os[0] = d[tile_idx].os; s->dim_tw[0] = d[tile_idx].tw;
+        if (d[tile_idx].is_batch) s->batch_dim = 0;
+        k = 1;
+    }
+    for (i = 0; i < nd; ++i) {
+        if (i == tile_idx) continue;
+        if (d[i].n == 1 && !d[i].is_batch) continue;
+        if (k >= FFTW_AMD_MAX_DIMS) { p->failed = 1; return -1; }
+        s->dim_n[k] = d[i].n; s->dim_is[k] = d[i].is;
+        s->dim_os[k] = d[i].os; s->dim_tw[k] = d[i].tw;
+        if (d[i].is_batch) s->batch_dim = k;
+        ++k;
+    }
+    s->ndims = k;
+    return 0;
+}
+
+/* One batched length-L DFT pass.  dims: every index other than the transform
+   index.  The tile dim is the one whose stride makes global access widest. */
+static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l,
+                      const sdim *dims, int nd, i64 tw_n, int flags) {
+    fftw_amd_step_desc *s = new_step(p, FFTW_AMD_STEP_PASS);
+    int i, best = -1;
+    i64 best_cost = 0, T;
+    const i64 INF = (i64)1 << 60;
+    sdim dummy;
+    for (i = 0; i < nd; ++i) {
+        i64 ci, co, cost;
+        if (dims[i].n <= 1) continue;
+        ci = dims[i].is ? iabs(dims[i].is) : INF;
+        co = dims[i].os ? iabs(dims[i].os) : INF;
+        if (L > 1 && iabs(is_l) < ci) ci = iabs(is_l);
+        if (L > 1 && iabs(os_l) < co) co = iabs(os_l);
+        cost = ci + co;
+        if (best < 0 || cost < best_cost ||
+            (cost == best_cost && dims[i].n > dims[best].n)) {
+            best = i;
+            best_cost = cost;
+        }
+    }
+    s->src_buf = src.buf; s->src_base = src.base; s->src_im = src.im;
+    s->dst_buf = dst.buf; s->dst_base = dst.base; s->dst_im = dst.im;
+    s->flags = flags;
+    s->L = (int)L;
+    s->is_l = is_l;
+    s->os_l = os_l;
+    s->nradices = fa_radices(L, s->radices);
+    if (s->nradices < 0) { p->failed = 1; return; }
+    if (L > 1) s->table = tab_stage(p, L);
+    if (best < 0) {
+        /* no loop with extent > 1: a dummy tile dim keeps the kernel uniform,
+           any batch dim of extent 1 still rides along as a loop */
+        sdim tmp[FFTW_AMD_MAX_DIMS + 1];
+        memset(&dummy, 0, sizeof(dummy));
+        dummy.n = 1;
+        tmp[0] = dummy;
+        for (i = 0; i < nd && i < FFTW_AMD_MAX_DIMS; ++i) tmp[i + 1] = dims[i];
+        step_set_dims(p, s, tmp, nd + 1, 0);
+    } else {
+        step_set_dims(p, s, dims, nd, best);
+    }
+    T = FA_TILE_ELEMS / L;
+    if (T < 1) T = 1;
+    if (T > s->dim_n[0]) T = s->dim_n[0];
+    if (T < 1) T = 1;
+    s->tile = (int)T;
+    s->tw_n = tw_n;
+    if (tw_n) tab_tw2(p, tw_n, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+    {
+        double work = (double)L;
+        for (i = 0; i < s->ndims; ++i) work *= (double)s->dim_n[i];
+        if (L > 1) p->est_flops += 5.0 * work * log2((double)L);
+        if (tw_n) p->est_flops += 6.0 * work;
+    }
+}
+
+static void emit_copy(plan *p, int kind, fa_loc src, fa_loc dst, i64 K, i64 Kvalid,
+                      i64 is_k, i64 os_k, const sdim *dims, int nd, int flags,
+                      int table, int table2) {
+    fftw_amd_step_desc *s = new_step(p, kind);
+    s->src_buf = src.buf; s->src_base = src.base; s->src_im = src.im;
+    s->dst_buf = dst.buf; s->dst_base = dst.base; s->dst_im = dst.im;
+    s->flags = flags;
+    s->is_l = is_k;
+    s->os_l = os_k;
+    s->aux_n = K;
+    s->aux_valid = Kvalid;
+    s->table = table;
+    s->table2 = table2;
+    step_set_dims(p, s, dims, nd, -1);
+}
+
+/* ------------------------------------------------------------- one axis */
+
+static void fa_emit_axis(plan *p, const fa_axis *ax);
+
+static int loops_to_sdims(const fa_axis *ax, sdim *d, int use_dst_as_src) {
+    int i;
+    for (i = 0; i < ax->nloops; ++i) {
+        d[i].n = ax->loops[i].n;
+        d[i].is = use_dst_as_src ? ax->loops[i].os : ax->loops[i].is;
+        d[i].os = ax->loops[i].os;
+        d[i].tw = 0;
+        d[i].is_batch = (i == ax->batch_loop);
+    }
+    return ax->nloops;
+}
+
+/* dense scratch layout for an axis: batch loop outermost, then the remaining
+   indices in the order of their source strides, innermost stride 2 (one
+   interleaved complex).  Returns total doubles; fills axis and loop strides. */
+static i64 scratch_layout(const fa_axis *ax, i64 n_axis, i64 *ts_axis, i64 *ts_loop) {
+    int order[FA_MAXLOOPS + 1], cnt = 0, i, j;
+    i64 key[FA_MAXLOOPS + 1], stride = 2;
+    /* index -1 denotes the axis itself */
+    for (i = 0; i < ax->nloops; ++i) {
+        if (i == ax->batch_loop) continue;
+        order[cnt] = i;
+        key[cnt] = iabs(ax->loops[i].is);
+        ++cnt;
+    }
+    order[cnt] = -1;
+    key[cnt] = iabs(ax->is);
+    ++cnt;
+    /* insertion sort ascending by source stride: smallest stride innermost */
+    for (i = 1; i < cnt; ++i) {
+        int o = order[i];
+        i64 k = key[i];
+        for (j = i - 1; j >= 0 && key[j] > k; --j) { order[j + 1] = order[j]; key[j + 1] = key[j]; }
+        order[j + 1] = o;
+        key[j + 1] = k;
+    }
+    for (i = 0; i < cnt; ++i) {
+        if (order[i] < 0) { *ts_axis = stride; stride *= n_axis; }
+        else { ts_loop[order[i]] = stride; stride *= ax->loops[order[i]].n; }
+    }
+    if (ax->batch_loop >= 0) {
+        ts_loop[ax->batch_loop] = stride;
+        stride *= ax->loops[ax->batch_loop].n;
+    }
+    return stride;
+}
+
+/* Cooley-Tukey over k >= 2 passes through a scratch image:
+   pass i < k : length-L_i DFTs down columns of the [L_i][M_i] view, times
+               w_{L_i M_i}^(k_i j);   last pass: length-L_k DFTs along rows,
+   written transposed so the output is in natural order. */
+static void emit_ct(plan *p, const fa_axis *ax, const i64 *lens, int k) {
+    i64 M[FA_MAXPASS + 1], Pf[FA_MAXPASS + 1];
+    i64 ts, lts[FA_MAXLOOPS], total;
+    sdim d[FFTW_AMD_MAX_DIMS + FA_MAXLOOPS];
+    fa_loc tmp;
+    int i, j, nd, tbuf;
+
+    /* M[i] = product of the lengths after pass i, Pf[i] = product before it */
+    M[k - 1] = 1;
+    for (i = k - 2; i >= 0; --i) M[i] = M[i + 1] * lens[i + 1];
+    Pf[0] = 1;
+    for (i = 1; i < k; ++i) Pf[i] = Pf[i - 1] * lens[i - 1];
+
+    total = scratch_layout(ax, ax->n, &ts, lts);
+    tbuf = buf_acquire(p, total);
+    tmp.buf = tbuf;
+    tmp.base = 0;
+    tmp.im = 1;
+
+    for (i = 0; i < k; ++i) {
+        int flags = 0;
+        nd = 0;
+        if (i == 0) {
+            /* source -> scratch */
+            d[nd].n = M[0]; d[nd].is = ax->is; d[nd].os = ts; d[nd].tw = 1; d[nd].is_batch = 0; ++nd;
+            for (j = 0; j < ax->nloops; ++j) {
+                d[nd].n = ax->loops[j].n; d[nd].is = ax->loops[j].is; d[nd].os = lts[j];
+                d[nd].tw = 0; d[nd].is_batch = (j == ax->batch_loop); ++nd;
+            }
+            flags = ax->flags_in & (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_REAL_IN);
+            emit_pass(p, ax->src, tmp, lens[0], M[0] * ax->is, M[0] * ts, d, nd, ax->n, flags);
+        } else if (i < k - 1) {
+            /* scratch -> scratch, in place */
+            d[nd].n = M[i]; d[nd].is = ts; d[nd].os = ts; d[nd].tw = 1; d[nd].is_batch = 0; ++nd;
+            for (j = 0; j < i; ++j) {
+                d[nd].n = lens[j]; d[nd].is = M[j] * ts; d[nd].os = M[j] * ts;
+                d[nd].tw = 0; d[nd].is_batch = 0; ++nd;
+            }
+            for (j = 0; j < ax->nloops; ++j) {
+                d[nd].n = ax->loops[j].n; d[nd].is = lts[j]; d[nd].os = lts[j];
+                d[nd].tw = 0; d[nd].is_batch = (j == ax->batch_loop); ++nd;
+            }
+            emit_pass(p, tmp, tmp, lens[i], M[i] * ts, M[i] * ts, d, nd, lens[i] * M[i], 0);
+        } else {
+            /* scratch -> destination, digits reversed into natural order */
+            for (j = 0; j < k - 1; ++j) {
+                d[nd].n = lens[j]; d[nd].is = M[j] * ts; d[nd].os = Pf[j] * ax->os;
+                d[nd].tw = 0; d[nd].is_batch = 0; ++nd;
+            }
+            for (j = 0; j < ax->nloops; ++j) {
+                d[nd].n = ax->loops[j].n; d[nd].is = lts[j]; d[nd].os = ax->loops[j].os;
+                d[nd].tw = 0; d[nd].is_batch = (j == ax->batch_loop); ++nd;
+            }
+            flags = ax->flags_out & (FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_REAL_OUT);
+            emit_pass(p, tmp, ax->dst, lens[k - 1], ts, Pf[k - 1] * ax->os, d, nd, 0, flags);
+        }
+    }
+    buf_release(p, tbuf);
+}
+
+/* Bluestein: y[k] = conj(w_k) * ( (x conj(w)) (*) w )[k], the convolution by
+   two DFTs of the smooth size nb >= 2n-1  (reference A.c:1642-1688) */
+static void emit_bluestein(plan *p, const fa_axis *ax) {
+    i64 n = ax->n, nb = fa_next_smooth(2 * n - 1);
+    i64 wts, lts[FA_MAXLOOPS], total;
+    int chirp = tab_chirp(p, n, nb);
+    int kern = tab_blue_kernel(p, n, nb);
+    int wbuf, j, nd;
+    fa_loc w;
+    sdim d[FA_MAXLOOPS];
+    fa_axis sub;
+
+    /* work image [loops][nb], axis innermost */
+    {
+        fa_axis lay = *ax;
+        lay.is = 1;   /* force the axis innermost in the scratch */
+        total = scratch_layout(&lay, nb, &wts, lts);
+    }
+    wbuf = buf_acquire(p, total);
+    w.buf = wbuf; w.base = 0; w.im = 1;
+
+    nd = 0;
+    for (j = 0; j < ax->nloops; ++j) {
+        d[nd].n = ax->loops[j].n; d[nd].is = ax->loops[j].is; d[nd].os = lts[j];
+        d[nd].tw = 0; d[nd].is_batch = (j == ax->batch_loop); ++nd;
+    }
+    emit_copy(p, FFTW_AMD_STEP_COPY, ax->src, w, nb, n, ax->is, wts, d, nd,
+              (ax->flags_in & (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_REAL_IN)) | FFTW_AMD_F_MUL_CONJ,
+              chirp, -1);
+
+    memset(&sub, 0, sizeof(sub));
+    sub.n = nb; sub.is = wts; sub.os = wts; sub.src = w; sub.dst = w;
+    sub.nloops = ax->nloops; sub.batch_loop = ax->batch_loop;
+    for (j = 0; j < ax->nloops; ++j) {
+        sub.loops[j].n = ax->loops[j].n; sub.loops[j].is = lts[j]; sub.loops[j].os = lts[j];
+    }
+    fa_emit_axis(p, &sub);
+
+    for (j = 0; j < nd; ++j) d[j].is = d[j].os;
+    emit_copy(p, FFTW_AMD_STEP_COPY, w, w, nb, nb, wts, wts, d, nd, FFTW_AMD_F_MUL_TABLE, kern, -1);
+
+    sub.flags_in = FFTW_AMD_F_SWAP_IN;
+    sub.flags_out = FFTW_AMD_F_SWAP_OUT;
+    fa_emit_axis(p, &sub);
+
+    for (j = 0; j < ax->nloops; ++j) { d[j].is = lts[j]; d[j].os = ax->loops[j].os; }
+    emit_copy(p, FFTW_AMD_STEP_COPY, w, ax->dst, n, n, wts, ax->os, d, nd,
+              (ax->flags_out & (FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_REAL_OUT)) | FFTW_AMD_F_MUL_CONJ,
+              chirp, -1);
+    buf_release(p, wbuf);
+}
+
+/* Rader for a prime p: a cyclic convolution of length p-1 over the
+   multiplicative group (reference rader_apply A.c:4187-4261) */
+static void emit_rader(plan *p, const fa_axis *ax) {
+    i64 pr = ax->n, m = pr - 1;
+    i64 wts, lts[FA_MAXLOOPS], xts, xlts[FA_MAXLOOPS], total, xtotal;
+    int pf = tab_perm(p, pr, 0), pinv = tab_perm(p, pr, 1);
+    int omega = tab_rader_kernel(p, pr);
+    int wbuf, xbuf, j, nd;
+    fa_loc w, x0;
+    sdim d[FA_MAXLOOPS];
+    fa_axis sub, lay;
+    fftw_amd_step_desc *s;
+
+    lay = *ax;
+    lay.is = 1;
+    total = scratch_layout(&lay, m, &wts, lts);
+    xtotal = scratch_layout(&lay, 1, &xts, xlts);
+    wbuf = buf_acquire(p, total);
+    xbuf = buf_acquire(p, xtotal);
+    w.buf = wbuf; w.base = 0; w.im = 1;
+    x0.buf = xbuf; x0.base = 0; x0.im = 1;
+
+    nd = 0;
+    for (j = 0; j < ax->nloops; ++j) {
+        d[nd].n = ax->loops[j].n; d[nd].is = ax->loops[j].is; d[nd].os = lts[j];
+        d[nd].tw = 0; d[nd].is_batch = (j == ax->batch_loop); ++nd;
+    }
+    /* a[k] = x[g^k] */
+    emit_copy(p, FFTW_AMD_STEP_COPY, ax->src, w, m, m, ax->is, wts, d, nd,
+              (ax->flags_in & (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_REAL_IN)) | FFTW_AMD_F_PERM_SRC,
+              -1, pf);
+    /* x0 */
+    for (j = 0; j < nd; ++j) d[j].os = xlts[j];
+    emit_copy(p, FFTW_AMD_STEP_COPY, ax->src, x0, 1, 1, ax->is, xts, d, nd,
+              ax->flags_in & (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_REAL_IN), -1, -1);
+
+    memset(&sub, 0, sizeof(sub));
+    sub.n = m; sub.is = wts; sub.os = wts; sub.src = w; sub.dst = w;
+    sub.nloops = ax->nloops; sub.batch_loop = ax->batch_loop;
+    for (j = 0; j < ax->nloops; ++j) {
+        sub.loops[j].n = ax->loops[j].n; sub.loops[j].is = lts[j]; sub.loops[j].os = lts[j];
+    }
+    fa_emit_axis(p, &sub);
+
+    /* pointwise product, DC fix-ups, Y[0].  The kernel walks vectors in the
+       scratch order, which is the order of dims given here. */
+    s = new_step(p, FFTW_AMD_STEP_RADER_MUL);
+    s->src_buf = wbuf; s->src_base = 0; s->src_im = 1;
+    s->dst_buf = ax->dst.buf; s->dst_base = ax->dst.base; s->dst_im = ax->dst.im;
+    s->aux_buf = xbuf; s->aux_base = 0;
+    s->aux_n = m;
+    s->table = omega;
+    s->flags = ax->flags_out & (FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_REAL_OUT);
+    {
+        /* dims sorted by scratch stride ascending so that the linear vector
+           index equals the scratch vector index */
+        sdim sd[FA_MAXLOOPS];
+        int order[FA_MAXLOOPS], a, b, t;
+        for (j = 0; j < ax->nloops; ++j) order[j] = j;
+        for (a = 0; a < ax->nloops; ++a)
+            for (b = a + 1; b < ax->nloops; ++b)
+                if (lts[order[b]] < lts[order[a]]) { t = order[a]; order[a] = order[b]; order[b] = t; }
+        for (j = 0; j < ax->nloops; ++j) {
+            int o = order[j];
+            sd[j].n = ax->loops[o].n; sd[j].is = lts[o]; sd[j].os = ax->loops[o].os;
+            sd[j].tw = 0; sd[j].is_batch = (o == ax->batch_loop);
+        }
+        /* keep extent-1 dims out but the vector numbering intact: extent 1
+           contributes a factor of 1 */
+        step_set_dims(p, s, sd, ax->nloops, -1);
+    }
+
+    sub.flags_in = FFTW_AMD_F_SWAP_IN;
+    sub.flags_out = FFTW_AMD_F_SWAP_OUT;
+    fa_emit_axis(p, &sub);
+
+    /* Y[g^-k] = c[k] */
+    for (j = 0; j < ax->nloops; ++j) { d[j].is = lts[j]; d[j].os = ax->loops[j].os; }
+    emit_copy(p, FFTW_AMD_STEP_COPY, w, ax->dst, m, m, wts, ax->os, d, nd,
+              (ax->flags_out & (FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_REAL_OUT)) | FFTW_AMD_F_PERM_DST,
+              -1, pinv);
+    buf_release(p, xbuf);
+    buf_release(p, wbuf);
+}
+
+static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
+    fa_axis ax = *ax_in;
+    i64 lens[FA_MAXPASS];
+    int k, contiguous;
+    sdim d[FA_MAXLOOPS];
+    i64 lmax1;
+
+    if (p->failed) return;
+
+    if (!fa_lds_able(ax.n)) {
+        if (fa_is_prime(ax.n) && fa_lds_able(ax.n - 1)) emit_rader(p, &ax);
+        else emit_bluestein(p, &ax);
+        return;
+    }
+    /* A strided axis keeps tiles at least 8 wide so that global access stays
+       in 128-byte segments; a contiguous axis may fill the tile by itself. */
+    contiguous = (iabs(ax.is) <= 2 && iabs(ax.os) <= 2);
+    lmax1 = contiguous ? FA_LMAX_SINGLE : FA_TILE_ELEMS / 8;
+    if (ax.nloops == 0 && !contiguous) lmax1 = FA_LMAX_SINGLE;
+    k = fa_factor_passes(ax.n, FA_MAXPASS, lmax1, contiguous ? g_lmax_multi : FA_TILE_ELEMS / 8, lens);
+    if (k == 0) {
+        /* e.g. a prime factor between lmax and FA_PRIME_LDS_MAX cannot happen;
+           sizes that do not split fall back to Bluestein */
+        emit_bluestein(p, &ax);
+        return;
+    }
+    if (k == 1) {
+        int nd = loops_to_sdims(&ax, d, 0);
+        emit_pass(p, ax.src, ax.dst, ax.n, ax.is, ax.os, d, nd, 0,
+                  (ax.flags_in & (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_REAL_IN)) |
+                  (ax.flags_out & (FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_REAL_OUT)));
+        return;
+    }
+    if (ax.nloops + k > FFTW_AMD_MAX_DIMS) { p->failed = 1; return; }
+    emit_ct(p, &ax, lens, k);
+}
+
+/* ------------------------------------------------------- whole problems */
+
+/* merge loop b into loop a when b is exactly a's inner continuation */
+static int merge_loops(fa_dim *l, int n, int *batch) {
+    int changed = 1;
+    while (changed) {
+        int a, b;
+        changed = 0;
+        for (a = 0; a < n && !changed; ++a)
+            for (b = 0; b < n && !changed; ++b) {
+                if (a == b || a == *batch || b == *batch) continue;
+                if (l[a].is == l[b].n * l[b].is && l[a].os == l[b].n * l[b].os) {
+                    int i;
+                    l[b].n *= l[a].n;
+                    for (i = a; i + 1 < n; ++i) l[i] = l[i + 1];
+                    if (*batch > a) --*batch;
+                    --n;
+                    changed = 1;
+                }
+            }
+    }
+    return n;
+}
+
+/* loops for transforming `axis` of a rank-r array: the other transform dims
+   plus the howmany dims.  use_os: source strides are the output strides. */
+static int collect_loops(const plan *p, const fa_dim *dims, int rank, int axis,
+                         const i64 *ext_override, int use_os, fa_axis *ax) {
+    int i, n = 0;
+    ax->batch_loop = -1;
+    for (i = 0; i < rank; ++i) {
+        if (i == axis) continue;
+        if (n >= FA_MAXLOOPS) return -1;
+        ax->loops[n].n = ext_override ? ext_override[i] : dims[i].n;
+        ax->loops[n].is = use_os ? dims[i].os : dims[i].is;
+        ax->loops[n].os = dims[i].os;
+        ++n;
+    }
+    for (i = 0; i < p->hrank; ++i) {
+        if (n >= FA_MAXLOOPS) return -1;
+        ax->loops[n].n = (i == 0) ? p->chunk : p->hdims[i].n;
+        ax->loops[n].is = use_os ? p->hdims[i].os : p->hdims[i].is;
+        ax->loops[n].os = p->hdims[i].os;
+        if (i == 0) ax->batch_loop = n;
+        ++n;
+    }
+    n = merge_loops(ax->loops, n, &ax->batch_loop);
+    ax->nloops = n;
+    return 0;
+}
+
+static void build_c2c(plan *p) {
+    int a, first = 1;
+    int sw_in = (p->sign > 0) ? FFTW_AMD_F_SWAP_IN : 0;
+    int sw_out = (p->sign > 0) ? FFTW_AMD_F_SWAP_OUT : 0;
+    fa_loc in = { 0, 0, p->in_im }, out = { 1, 0, p->out_im };
+    if (p->rank == 0) {
+        /* rank-0 "transform" = strided copy (reference rank0 solvers) */
+        fa_axis ax;
+        sdim d[FA_MAXLOOPS];
+        int nd;
+        memset(&ax, 0, sizeof(ax));
+        if (collect_loops(p, p->dims, 0, -1, NULL, 0, &ax)) { p->failed = 1; return; }
+        nd = loops_to_sdims(&ax, d, 0);
+        emit_pass(p, in, out, 1, 0, 0, d, nd, 0, 0);
+        return;
+    }
+    for (a = p->rank - 1; a >= 0; --a) {
+        fa_axis ax;
+        memset(&ax, 0, sizeof(ax));
+        ax.n = p->dims[a].n;
+        ax.is = first ? p->dims[a].is : p->dims[a].os;
+        ax.os = p->dims[a].os;
+        ax.src = first ? in : out;
+        ax.dst = out;
+        ax.flags_in = sw_in;
+        ax.flags_out = sw_out;
+        if (collect_loops(p, p->dims, p->rank, a, NULL, !first, &ax)) { p->failed = 1; return; }
+        fa_emit_axis(p, &ax);
+        first = 0;
+    }
+}
+
+/* r2c: last dim real -> half spectrum, then complex DFTs over the other dims
+   on the half-spectrum array (reference rank_geq2_rdft2 A.c:10111-10282).
+   p->dims[].is are strides of the REAL array (doubles), .os of the complex
+   array (doubles, so 2 per complex). */
+static void build_r2c(plan *p) {
+    int r = p->rank, a, j;
+    i64 nl = p->dims[r - 1].n, half = nl / 2 + 1;
+    i64 ext[FA_MAXRANK];
+    fa_loc in = { 0, 0, 0 }, out = { 1, 0, p->out_im };
+    fa_axis ax;
+    for (j = 0; j < r; ++j) ext[j] = p->dims[j].n;
+    ext[r - 1] = half;
+
+    memset(&ax, 0, sizeof(ax));
+    if (collect_loops(p, p->dims, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
+
+    if (nl % 2 == 0 && nl >= 2) {
+        /* z[j] = x[2j] + i x[2j+1]; Z = DFT_{n/2}(z); untangle */
+        i64 h = nl / 2, zts, lts[FA_MAXLOOPS], total;
+        int zbuf, nd;
+        fa_loc z;
+        fa_axis half_ax = ax, lay;
+        sdim d[FA_MAXLOOPS];
+        fftw_amd_step_desc *s;
+        lay = ax;
+        lay.is = 1;
+        total = scratch_layout(&lay, h, &zts, lts);
+        zbuf = buf_acquire(p, total);
+        z.buf = zbuf; z.base = 0; z.im = 1;
+
+        half_ax.n = h;
+        half_ax.is = 2 * p->dims[r - 1].is;
+        half_ax.os = zts;
+        half_ax.src = in;
+        half_ax.src.im = p->dims[r - 1].is;     /* odd sample = imaginary part */
+        half_ax.dst = z;
+        for (j = 0; j < ax.nloops; ++j) half_ax.loops[j].os = lts[j];
+        fa_emit_axis(p, &half_ax);
+
+        s = new_step(p, FFTW_AMD_STEP_R2C_POST);
+        s->src_buf = zbuf; s->src_base = 0; s->src_im = 1;
+        s->dst_buf = 1; s->dst_base = 0; s->dst_im = p->out_im;
+        s->is_l = zts;
+        s->os_l = p->dims[r - 1].os;
+        s->aux_n = nl;
+        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        nd = 0;
+        for (j = 0; j < ax.nloops; ++j) {
+            d[nd].n = ax.loops[j].n; d[nd].is = lts[j]; d[nd].os = ax.loops[j].os;
+            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+        }
+        step_set_dims(p, s, d, nd, -1);
+        p->est_flops += 8.0 * (double)h;
+        buf_release(p, zbuf);
+    } else {
+        /* odd length: full complex DFT of the real sequence, keep half */
+        i64 fts, lts[FA_MAXLOOPS], total;
+        int fbuf, nd;
+        fa_loc f;
+        fa_axis full_ax = ax, lay;
+        sdim d[FA_MAXLOOPS];
+        lay = ax;
+        lay.is = 1;
+        total = scratch_layout(&lay, nl, &fts, lts);
+        fbuf = buf_acquire(p, total);
+        f.buf = fbuf; f.base = 0; f.im = 1;
+        full_ax.n = nl;
+        full_ax.is = p->dims[r - 1].is;
+        full_ax.os = fts;
+        full_ax.src = in;
+        full_ax.dst = f;
+        full_ax.flags_in = FFTW_AMD_F_REAL_IN;
+        for (j = 0; j < ax.nloops; ++j) full_ax.loops[j].os = lts[j];
+        fa_emit_axis(p, &full_ax);
+        nd = 0;
+        for (j = 0; j < ax.nloops; ++j) {
+            d[nd].n = ax.loops[j].n; d[nd].is = lts[j]; d[nd].os = ax.loops[j].os;
+            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+        }
+        emit_copy(p, FFTW_AMD_STEP_COPY, f, out, half, half, fts, p->dims[r - 1].os, d, nd, 0, -1, -1);
+        buf_release(p, fbuf);
+    }
+
+    for (a = r - 2; a >= 0; --a) {
+        fa_axis cx;
+        memset(&cx, 0, sizeof(cx));
+        cx.n = p->dims[a].n;
+        cx.is = cx.os = p->dims[a].os;
+        cx.src = cx.dst = out;
+        if (collect_loops(p, p->dims, r, a, ext, 1, &cx)) { p->failed = 1; return; }
+        fa_emit_axis(p, &cx);
+    }
+}
+
+/* c2r: complex backward DFTs over the leading dims (into scratch, so the
+   caller's input survives), then half spectrum -> real along the last dim.
+   p->dims[].is: strides of the complex array, .os: of the real array. */
+static void build_c2r(plan *p) {
+    int r = p->rank, a, j;
+    i64 nl = p->dims[r - 1].n, half = nl / 2 + 1;
+    i64 ext[FA_MAXRANK];
+    fa_loc in = { 0, 0, p->in_im }, out = { 1, 0, 0 };
+    fa_loc cur = in;
+    fa_dim cdims[FA_MAXRANK];     /* current layout of the half-spectrum array */
+    fa_dim chd[FA_MAXRANK];
+    int cbuf = -1;
+    fa_axis ax;
+
+    for (j = 0; j < r; ++j) { ext[j] = p->dims[j].n; cdims[j] = p->dims[j]; cdims[j].os = p->dims[j].is; }
+    ext[r - 1] = half;
+    for (j = 0; j < p->hrank; ++j) { chd[j] = p->hdims[j]; chd[j].os = p->hdims[j].is; }
+
+    if (r > 1) {
+        /* dense scratch for the half spectrum: [batch][d0]...[half] */
+        i64 stride = 2, total;
+        fa_dim sd[FA_MAXRANK], sh[FA_MAXRANK];
+        plan view;
+        int first = 1;
+        for (j = r - 1; j >= 0; --j) { sd[j].n = ext[j]; sd[j].os = stride; stride *= ext[j]; }
+        for (j = p->hrank - 1; j >= 1; --j) { sh[j].n = p->hdims[j].n; sh[j].os = stride; stride *= p->hdims[j].n; }
+        if (p->hrank) { sh[0].n = p->hdims[0].n; sh[0].os = stride; stride *= p->chunk; }
+        total = stride;
+        cbuf = buf_acquire(p, total);
+        /* leading dims: in -> scratch for the first, in place afterwards */
+        for (a = r - 2; a >= 0; --a) {
+            fa_axis cx;
+            fa_dim td[FA_MAXRANK];
+            memset(&cx, 0, sizeof(cx));
+            for (j = 0; j < r; ++j) {
+                td[j].n = ext[j];
+                td[j].is = first ? p->dims[j].is : sd[j].os;
+                td[j].os = sd[j].os;
+            }
+            view = *p;
+            for (j = 0; j < p->hrank; ++j) {
+                view.hdims[j].is = first ? p->hdims[j].is : sh[j].os;
+                view.hdims[j].os = sh[j].os;
+            }
+            cx.n = p->dims[a].n;
+            cx.is = td[a].is;
+            cx.os = td[a].os;
+            cx.src = first ? in : (fa_loc){ cbuf, 0, 1 };
+            cx.dst = (fa_loc){ cbuf, 0, 1 };
+            cx.flags_in = FFTW_AMD_F_SWAP_IN;
+            cx.flags_out = FFTW_AMD_F_SWAP_OUT;
+            if (collect_loops(&view, td, r, a, ext, 0, &cx)) { p->failed = 1; return; }
+            fa_emit_axis(p, &cx);
+            first = 0;
+        }
+        cur = (fa_loc){ cbuf, 0, 1 };
+        for (j = 0; j < r; ++j) { cdims[j].is = sd[j].os; }
+        for (j = 0; j < p->hrank; ++j) chd[j].is = sh[j].os;
+    }
+
+    /* loops of the last-dim c2r: source strides = current complex layout,
+       destination strides = the real output array */
+    memset(&ax, 0, sizeof(ax));
+    {
+        plan view = *p;
+        fa_dim td[FA_MAXRANK];
+        for (j = 0; j < r; ++j) { td[j].n = p->dims[j].n; td[j].is = cdims[j].is; td[j].os = p->dims[j].os; }
+        for (j = 0; j < p->hrank; ++j) { view.hdims[j].is = chd[j].is; view.hdims[j].os = p->hdims[j].os; }
+        if (collect_loops(&view, td, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
+    }
+
+    if (nl % 2 == 0 && nl >= 2) {
+        i64 h = nl / 2, zts, lts[FA_MAXLOOPS], total;
+        int zbuf, nd;
+        fa_loc z;
+        fa_axis half_ax, lay;
+        sdim d[FA_MAXLOOPS];
+        fftw_amd_step_desc *s;
+        lay = ax;
+        lay.is = 1;
+        total = scratch_layout(&lay, h, &zts, lts);
+        zbuf = buf_acquire(p, total);
+        z.buf = zbuf; z.base = 0; z.im = 1;
+
+        s = new_step(p, FFTW_AMD_STEP_C2R_PRE);
+        s->src_buf = cur.buf; s->src_base = cur.base; s->src_im = cur.im;
+        s->dst_buf = zbuf; s->dst_base = 0; s->dst_im = 1;
+        s->is_l = cdims[r - 1].is;
+        s->os_l = zts;
+        s->aux_n = nl;
+        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        nd = 0;
+        for (j = 0; j < ax.nloops; ++j) {
+            d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
+            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+        }
+        step_set_dims(p, s, d, nd, -1);
+
+        half_ax = ax;
+        half_ax.n = h;
+        half_ax.is = zts;
+        half_ax.os = 2 * p->dims[r - 1].os;
+        half_ax.src = z;
+        half_ax.dst = out;
+        half_ax.dst.im = p->dims[r - 1].os;
+        half_ax.flags_in = FFTW_AMD_F_SWAP_IN;
+        half_ax.flags_out = FFTW_AMD_F_SWAP_OUT;
+        for (j = 0; j < ax.nloops; ++j) half_ax.loops[j].is = lts[j];
+        fa_emit_axis(p, &half_ax);
+        buf_release(p, zbuf);
+    } else {
+        i64 fts, lts[FA_MAXLOOPS], total;
+        int fbuf, nd;
+        fa_loc f;
+        fa_axis full_ax, lay;
+        sdim d[FA_MAXLOOPS];
+        lay = ax;
+        lay.is = 1;
+        total = scratch_layout(&lay, nl, &fts, lts);
+        fbuf = buf_acquire(p, total);
+        f.buf = fbuf; f.base = 0; f.im = 1;
+        nd = 0;
+        for (j = 0; j < ax.nloops; ++j) {
+            d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
+            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+        }
+        emit_copy(p, FFTW_AMD_STEP_HERM_EXPAND, cur, f, nl, nl, cdims[r - 1].is, fts, d, nd, 0, -1, -1);
+        full_ax = ax;
+        full_ax.n = nl;
+        full_ax.is = fts;
+        full_ax.os = p->dims[r - 1].os;
+        full_ax.src = f;
+        full_ax.dst = out;
+        full_ax.flags_in = FFTW_AMD_F_SWAP_IN;
+        /* backward by the swap identity: the real result is the imaginary
+           slot of the swapped output, so swap on store and keep the real part */
+        full_ax.flags_out = FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_REAL_OUT;
+        for (j = 0; j < ax.nloops; ++j) full_ax.loops[j].is = lts[j];
+        fa_emit_axis(p, &full_ax);
+        buf_release(p, fbuf);
+    }
+    if (cbuf >= 0) buf_release(p, cbuf);
+}
+
+static void build_steps(plan *p) {
+    switch (p->type) {
+    case FA_C2C: build_c2c(p); break;
+    case FA_R2C: build_r2c(p); break;
+    case FA_C2R: build_c2r(p); break;
+    default: p->failed = 1;
+    }
+}
+
+int fa_build(plan *p) {
+    i64 per_elem = 0;
+    int i;
+    p->batch = p->hrank ? p->hdims[0].n : 1;
+    if (p->batch == 0) {   /* howmany == 0: a valid plan that does nothing */
+        plan_reset_build(p);
+        p->chunk = 0;
+        return 0;
+    }
+    /* dry run at one batch element to size the scratch, then pick the chunk */
+    plan_reset_build(p);
+    p->chunk = 1;
+    build_steps(p);
+    if (p->failed) return -1;
+    for (i = 2; i < p->nbufs; ++i) per_elem += p->buf_reals[i];
+    if (per_elem == 0 || p->batch == 1 || p->single_chunk) {
+        p->chunk = p->batch;
+    } else {
+        i64 c = (i64)(g_chunk_bytes / ((size_t)per_elem * sizeof(double)));
+        if (c < 1) c = 1;
+        if (c > p->batch) c = p->batch;
+        p->chunk = c;
+    }
+    if (p->chunk != 1) {
+        plan_reset_build(p);
+        build_steps(p);
+        if (p->failed) return -1;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- device */
+
+static plan *make_c2c_1d_contig(i64 n) {
+    plan *q = fa_plan_new();
+    q->type = FA_C2C;
+    q->sign = FFTW_FORWARD;
+    q->rank = 1;
+    q->dims[0].n = n; q->dims[0].is = 2; q->dims[0].os = 2;
+    q->hrank = 0;
+    if (fa_build(q)) { fa_plan_free(q); return NULL; }
+    return q;
+}
+
+int fa_device_init(plan *p) {
+    int i;
+    if (p->dev_ready) return 0;
+    if (fa_hip_device_count() <= 0) {
+        fprintf(stderr, "fftw3_amd: no HIP device available: this executor has no CPU "
+                        "fallback; fftw_execute cannot run\n");
+        return -1;
+    }
+    for (i = 0; i < p->ntabs; ++i) {
+        fa_table *t = &p->tabs[i];
+        size_t bytes = (size_t)t->len * (t->kind == FA_TAB_PERM ? sizeof(i64) : 2 * sizeof(double));
+        if (t->dev) continue;
+        t->dev = fa_hip_malloc(bytes);
+        if (t->kind == FA_TAB_DFT_OF) continue;    /* second sweep */
+        fa_hip_memcpy_h2d(t->dev, t->host, bytes, p->stream);
+    }
+    fa_hip_stream_sync(p->stream);
+    for (i = 0; i < p->ntabs; ++i) {
+        fa_table *t = &p->tabs[i];
+        if (t->kind != FA_TAB_DFT_OF) continue;
+        {
+            /* the convolution kernel is itself a DFT: compute it with a
+               nested plan on the device, keep a host copy for introspection */
+            plan *q = make_c2c_1d_contig(t->n);
+            size_t bytes = (size_t)t->len * 2 * sizeof(double);
+            if (!q) return -1;
+            q->stream = p->stream;
+            fa_run(q, (double *)p->tabs[t->src].dev, (double *)p->tabs[t->src].dev + 1,
+                   (double *)t->dev, (double *)t->dev + 1);
+            if (!t->host) t->host = malloc(bytes);
+            fa_hip_memcpy_d2h(t->host, t->dev, bytes, p->stream);
+            fa_hip_stream_sync(p->stream);
+            fa_plan_free(q);
+        }
+    }
+    for (i = 2; i < p->nbufs; ++i)
+        if (!p->dbuf[i]) p->dbuf[i] = (double *)fa_hip_malloc((size_t)p->buf_reals[i] * sizeof(double));
+    p->dev_ready = 1;
+    return 0;
+}
+
+static double *stage_buf(double **slot, size_t *have, size_t need) {
+    if (*have < need) {
+        fa_hip_free(*slot);
+        *slot = (double *)fa_hip_malloc(need);
+        *have = need;
+    }
+    return *slot;
+}
+
+void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
+    double *bufs[FA_MAXBUF];
+    void *tabs[FA_MAXTAB];
+    int i, in_host = 0, out_host = 0;
+    i64 cs;
+    i64 in_im = ii - ri, out_im = io - ro;
+    double *din = ri, *dout = ro;
+    i64 in_span_lo = p->in_lo, in_span_hi = p->in_hi;
+    i64 out_span_lo = p->out_lo, out_span_hi = p->out_hi;
+
+    if (p->batch == 0) return;
+    if (fa_device_init(p)) abort();
+
+    if (p->type == FA_R2C) in_im = 0;
+    if (p->type == FA_C2R) out_im = 0;
+
+    /* plain host arrays are staged through device copies (slow path, PCIe) */
+    in_host = !fa_hip_is_device_ptr(ri);
+    out_host = !fa_hip_is_device_ptr(ro);
+    if (in_host) {
+        /* one contiguous span covering real and imaginary parts */
+        i64 lo = in_span_lo, hi = in_span_hi;
+        size_t bytes;
+        if (in_im > 0) hi += in_im; else lo += in_im;
+        bytes = (size_t)(hi - lo + 1) * sizeof(double);
+        din = stage_buf(&p->stage_in, &p->stage_in_bytes, bytes);
+        fa_hip_memcpy_h2d(din, ri + lo, bytes, p->stream);
+        din -= lo;
+    }
+    if (out_host) {
+        i64 lo = out_span_lo, hi = out_span_hi;
+        size_t bytes;
+        if (out_im > 0) hi += out_im; else lo += out_im;
+        bytes = (size_t)(hi - lo + 1) * sizeof(double);
+        if (in_host && ro == ri && io == ii) {
+            dout = din;                           /* in place */
+        } else {
+            dout = stage_buf(&p->stage_out, &p->stage_out_bytes, bytes);
+            /* gaps between output elements must survive the round trip */
+            if ((i64)(bytes / sizeof(double)) != p->out_written)
+                fa_hip_memcpy_h2d(dout, ro + lo, bytes, p->stream);
+            dout -= lo;
+        }
+    }
+
+    bufs[0] = din;
+    bufs[1] = dout;
+    for (i = 2; i < p->nbufs; ++i) bufs[i] = p->dbuf[i];
+    for (i = 0; i < p->ntabs; ++i) tabs[i] = p->tabs[i].dev;
+
+    for (cs = 0; cs < p->batch; cs += p->chunk) {
+        i64 cn = p->batch - cs < p->chunk ? p->batch - cs : p->chunk;
+        for (i = 0; i < p->nsteps; ++i) {
+            fftw_amd_step_desc d = p->steps[i];
+            /* split-array callers may pass different re/im distances per call */
+            if (d.src_buf == 0 && p->type != FA_R2C && d.src_im == p->in_im) d.src_im = in_im;
+            if (d.dst_buf == 1 && p->type != FA_C2R && d.dst_im == p->out_im) d.dst_im = out_im;
+            if (fa_hip_launch_step(&d, bufs, tabs, cs, cn, p->stream)) abort();
+        }
+    }
+
+    if (out_host) {
+        i64 lo = out_span_lo, hi = out_span_hi;
+        size_t bytes;
+        if (out_im > 0) hi += out_im; else lo += out_im;
+        bytes = (size_t)(hi - lo + 1) * sizeof(double);
+        fa_hip_memcpy_d2h(ro + lo, dout + lo, bytes, p->stream);
+    }
+    if (in_host || out_host) fa_hip_stream_sync(p->stream);
+}
+
+/* ------------------------------------------------------------- printing */
+
+static const char *kind_name(int k) {
+    switch (k) {
+    case FFTW_AMD_STEP_PASS: return "pass";
+    case FFTW_AMD_STEP_COPY: return "copy";
+    case FFTW_AMD_STEP_R2C_POST: return "r2c-untangle";
+    case FFTW_AMD_STEP_C2R_PRE: return "c2r-tangle";
+    case FFTW_AMD_STEP_RADER_MUL: return "rader-mul";
+    case FFTW_AMD_STEP_HERM_EXPAND: return "herm-expand";
+    }
+    return "?";
+}
+
+/* lisp-like dump in the spirit of the reference's fftw_print_plan
+   (fftw/fftw_api.c:1046-1080) */
+char *fa_sprint(const plan *p) {
+    size_t cap = 256 + (size_t)p->nsteps * 256, len = 0;
+    char *s = (char *)malloc(cap);
+    int i, j;
+    const char *tn = p->type == FA_C2C ? "dft" : p->type == FA_R2C ? "rdft2-r2c" : "rdft2-c2r";
+    len += (size_t)snprintf(s + len, cap - len, "(hip-%s batch=%lld chunk=%lld", tn, p->batch, p->chunk);
+    for (i = 0; i < p->nsteps; ++i) {
+        const fftw_amd_step_desc *d = &p->steps[i];
+        len += (size_t)snprintf(s + len, cap - len, "\n  (%s", kind_name(d->kind));
+        if (d->kind == FFTW_AMD_STEP_PASS) {
+            len += (size_t)snprintf(s + len, cap - len, "-%d/", d->L);
+            for (j = 0; j < d->nradices; ++j)
+                len += (size_t)snprintf(s + len, cap - len, "%s%d", j ? "x" : "", d->radices[j]);
+            len += (size_t)snprintf(s + len, cap - len, " tile=%d", d->tile);
+            if (d->tw_n) len += (size_t)snprintf(s + len, cap - len, " tw=%lld", d->tw_n);
+        } else {
+            len += (size_t)snprintf(s + len, cap - len, " n=%lld", d->aux_n);
+        }
+        len += (size_t)snprintf(s + len, cap - len, " buf%d->buf%d x", d->src_buf, d->dst_buf);
+        for (j = 0; j < d->ndims; ++j)
+            len += (size_t)snprintf(s + len, cap - len, "%s%lld", j ? "," : "", d->dim_n[j]);
+        len += (size_t)snprintf(s + len, cap - len, ")");
+    }
+    len += (size_t)snprintf(s + len, cap - len, ")");
+    return s;
+}

@@ -1,0 +1,120 @@
+/*
+ * fftw3_amd.h -- MI355X-specific additions behind the FFTW3 C ABI.
+ *
+ * Nothing here exists in the reference ("GPU-specific
+ * additions behind the same ABI"); the names live under the fftw_amd_ prefix so
+ * the stock fftw_ namespace stays clean.  All signatures are plain C: pointers,
+ * sizes and an opaque stream handle (a hipStream_t passed as void*).
+ */
+#ifndef FFTW3_AMD_EXT_H
+#define FFTW3_AMD_EXT_H
+
+#include <stddef.h>
+#include "fftw3.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Number of HIP devices visible to the process; 0 when there is none (the
+   planners still work, fftw_execute* aborts loudly: there is no CPU fallback). */
+int fftw_amd_device_count(void);
+
+/* Device memory (hipMalloc / hipFree).  fftw_execute* accepts these pointers
+   and runs on them in place of staging through PCIe.  fftw_malloc() itself
+   returns pinned host memory so CPU callers keep working (staged path). */
+void *fftw_amd_malloc_device(size_t nbytes);
+void  fftw_amd_free_device(void *p);
+
+/* Bind the HIP stream (hipStream_t as void*) that fftw_execute* launches on.
+   NULL restores the default stream.  Per plan. */
+void fftw_amd_plan_set_stream(fftw_plan p, void *hip_stream);
+
+/* Block until everything launched by fftw_execute*(p) has finished. */
+void fftw_amd_plan_sync(fftw_plan p);
+
+/* Bytes of device scratch the plan owns (twiddle tables + work buffers). */
+size_t fftw_amd_plan_workspace_bytes(const fftw_plan p);
+
+/* Upper bound, in bytes, for the scratch that one chunk of a multi-pass plan
+   may occupy (default 64 MiB: the intermediate of a two-pass transform then
+   stays in the 256 MiB Infinity Cache).  Affects plans created afterwards. */
+void fftw_amd_set_chunk_bytes(size_t nbytes);
+
+/* ---- plan introspection used by the host-logic tests ------------------- */
+
+#define FFTW_AMD_MAX_DIMS 8
+#define FFTW_AMD_MAX_RADICES 16
+
+/* One launch of the executor, as the planner built it.  Offsets and strides
+   are counted in doubles (an interleaved complex array has stride 2, im = 1). */
+typedef struct {
+    int kind;            /* FFTW_AMD_STEP_* */
+    int src_buf, dst_buf;/* 0 = plan input, 1 = plan output, 2.. = scratch */
+    long long src_base, dst_base;
+    long long src_im, dst_im;     /* distance from real to imaginary part */
+    int flags;                    /* FFTW_AMD_F_* */
+    int L;                        /* sub-transform length of a PASS */
+    int nradices, radices[FFTW_AMD_MAX_RADICES];
+    long long is_l, os_l;         /* stride of the transform index */
+    int ndims;                    /* dims[0] is the tile dim, the rest loops */
+    long long dim_n[FFTW_AMD_MAX_DIMS];
+    long long dim_is[FFTW_AMD_MAX_DIMS];
+    long long dim_os[FFTW_AMD_MAX_DIMS];
+    long long dim_tw[FFTW_AMD_MAX_DIMS];
+    long long tw_n;               /* 0: no inter-pass twiddle */
+    int tw_shift, tw_lo, tw_hi;   /* two-level table: w^m = lo[m & mask] * hi[m >> shift] */
+    int tile;                     /* tile width T along dims[0] */
+    int batch_dim;                /* index into dims of the chunked batch loop, or -1 */
+    long long aux_n;              /* kind-specific length (r2c: n, copy: K ...) */
+    long long aux_valid;          /* copy: source elements beyond this read as 0 */
+    int table, table2;            /* stage-twiddle / multiplier table, permutation table; -1: none */
+    int aux_buf;                  /* Rader: buffer holding x[0] per vector */
+    long long aux_base;
+    int variant;                  /* which kernel the executor launches (FFTW_AMD_K_*) */
+} fftw_amd_step_desc;
+
+enum {
+    FFTW_AMD_STEP_PASS = 1,     /* batched length-L DFT + optional twiddle */
+    FFTW_AMD_STEP_COPY = 2,     /* strided copy / pad / table multiply / permute */
+    FFTW_AMD_STEP_R2C_POST = 3, /* untangle half-length complex DFT into r2c output */
+    FFTW_AMD_STEP_C2R_PRE = 4,  /* inverse of the above */
+    FFTW_AMD_STEP_RADER_MUL = 5,/* Rader pointwise product and DC fix-ups */
+    FFTW_AMD_STEP_HERM_EXPAND = 6 /* half spectrum -> full Hermitian spectrum */
+};
+
+enum {
+    FFTW_AMD_K_GENERIC = 0      /* runtime-radix LDS kernel */
+};
+
+enum {
+    FFTW_AMD_F_SWAP_IN   = 1 << 0, /* read (im,re) instead of (re,im) */
+    FFTW_AMD_F_SWAP_OUT  = 1 << 1, /* write (im,re) */
+    FFTW_AMD_F_REAL_IN   = 1 << 2, /* source has no imaginary part (reads as 0) */
+    FFTW_AMD_F_REAL_OUT  = 1 << 3, /* store the real part only */
+    FFTW_AMD_F_MUL_TABLE = 1 << 4, /* copy: multiply by table[k] */
+    FFTW_AMD_F_MUL_CONJ  = 1 << 5, /* copy: multiply by conj(table[k]) */
+    FFTW_AMD_F_PERM_SRC  = 1 << 6, /* copy: source index through permutation */
+    FFTW_AMD_F_PERM_DST  = 1 << 7, /* copy: destination index through permutation */
+    FFTW_AMD_F_CONJ_OUT  = 1 << 8  /* conjugate on store */
+};
+
+int fftw_amd_plan_num_steps(const fftw_plan p);
+int fftw_amd_plan_get_step(const fftw_plan p, int i, fftw_amd_step_desc *out);
+/* how many batch elements one chunk processes, and the total batch */
+long long fftw_amd_plan_chunk(const fftw_plan p);
+long long fftw_amd_plan_batch(const fftw_plan p);
+/* host copy of table `id` as interleaved doubles; returns its length in
+   doubles (writes at most cap doubles). */
+long long fftw_amd_plan_table(const fftw_plan p, int id, double *dst, long long cap);
+
+/* Host-side numerics exported for the tests (no device needed). */
+void fftw_amd_cexp(long long m, long long n, double out[2]);  /* (cos, sin)(2 pi m / n) */
+long long fftw_amd_find_generator(long long p);
+long long fftw_amd_power_mod(long long b, long long e, long long p);
+int fftw_amd_factor_passes(long long n, int max_passes, long long *lens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

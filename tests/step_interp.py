@@ -1,0 +1,239 @@
+"""Test infrastructure: a numpy interpreter of the planner's step list.
+
+It executes, on the CPU, exactly what each kernel launch is *specified* to do
+(addressing, flags, twiddle tables, chunk loop) using numpy for the arithmetic.
+It exists so that the host logic -- the planner in fftw3_amd/csrc/planner.c --
+can be checked in the CPU-only test tier, where no HIP device is present.  It is
+never imported by the product (fftw3_amd/) and is not a fallback: the library
+itself can only execute on a GPU.
+"""
+import numpy as np
+
+import fftw3_amd as fa
+
+
+def _grids(sizes):
+    """index grids for the given extents, broadcastable against each other"""
+    n = len(sizes)
+    out = []
+    for k, s in enumerate(sizes):
+        shape = [1] * n
+        shape[k] = s
+        out.append(np.arange(s, dtype=np.int64).reshape(shape))
+    return out
+
+
+def _load(buf, off, im, flags):
+    re = buf[off]
+    imv = np.zeros_like(re) if (flags & fa.F_REAL_IN) else buf[off + im]
+    if flags & fa.F_SWAP_IN:
+        re, imv = imv, re
+    return re + 1j * imv
+
+
+def _store(buf, off, im, flags, v):
+    if flags & fa.F_CONJ_OUT:
+        v = np.conj(v)
+    re, imv = v.real, v.imag
+    if flags & fa.F_SWAP_OUT:
+        re, imv = imv, re
+    off = np.broadcast_to(off, v.shape)
+    buf[off] = re
+    if not (flags & fa.F_REAL_OUT):
+        buf[off + im] = imv
+
+
+class Interp(object):
+    def __init__(self, plan):
+        self.plan = plan
+        self.steps = plan.steps()
+        self.tables = {}
+
+    def table(self, tid):
+        if tid in self.tables:
+            return self.tables[tid]
+        t = self.plan.table(tid)
+        if isinstance(t, tuple):            # DFT of another table (device-computed in the product)
+            src = self.table(t[1])
+            t = np.fft.fft(src)
+        elif t.dtype == np.float64 and tid in self._perm_ids():
+            t = t.astype(np.int64)
+        else:
+            t = t[0::2] + 1j * t[1::2]
+        self.tables[tid] = t
+        return t
+
+    def _perm_ids(self):
+        ids = set()
+        for s in self.steps:
+            if s.kind == fa.STEP_COPY and s.table2 >= 0:
+                ids.add(s.table2)
+        return ids
+
+    def tw2(self, s, m):
+        lo = self.table(s.tw_lo)
+        hi = self.table(s.tw_hi)
+        mask = (1 << s.tw_shift) - 1
+        return lo[m & mask] * hi[m >> s.tw_shift]
+
+    def run(self, inbuf, outbuf, scratch_reals):
+        """inbuf/outbuf: flat float64 views of the user arrays (may be the same object)."""
+        bufs = {0: inbuf, 1: outbuf}
+        batch, chunk = self.plan.batch, self.plan.chunk
+        if batch == 0:
+            return
+        for cs in range(0, batch, chunk):
+            cn = min(chunk, batch - cs)
+            for s in self.steps:
+                for b in (s.src_buf, s.dst_buf, s.aux_buf):
+                    if b >= 2 and b not in bufs:
+                        bufs[b] = np.zeros(scratch_reals, dtype=np.float64)
+                self.step(s, bufs, cs, cn)
+
+    def _dims(self, s, cs, cn):
+        nd = s.ndims
+        dn = [s.dim_n[i] for i in range(nd)]
+        dis = [s.dim_is[i] for i in range(nd)]
+        dos = [s.dim_os[i] for i in range(nd)]
+        dtw = [s.dim_tw[i] for i in range(nd)]
+        sbase, dbase = s.src_base, s.dst_base
+        bd = s.batch_dim
+        if bd >= 0:
+            if s.src_buf < 2:
+                sbase += cs * dis[bd]
+            if s.dst_buf < 2:
+                dbase += cs * dos[bd]
+            dn[bd] = cn
+        return dn, dis, dos, dtw, sbase, dbase
+
+    def step(self, s, bufs, cs, cn):
+        dn, dis, dos, dtw, sbase, dbase = self._dims(s, cs, cn)
+        src, dst = bufs[s.src_buf], bufs[s.dst_buf]
+        if s.kind == fa.STEP_PASS:
+            L = s.L
+            g = _grids([L] + dn)
+            l, idx = g[0], g[1:]
+            soff = sbase + l * s.is_l
+            doff = dbase + l * s.os_l
+            twb = np.zeros_like(l)
+            for i, gi in enumerate(idx):
+                soff = soff + gi * dis[i]
+                doff = doff + gi * dos[i]
+                twb = twb + gi * dtw[i]
+            rad = [s.radices[i] for i in range(s.nradices)]
+            assert int(np.prod(rad)) == L if rad else L == 1
+            x = _load(src, soff, s.src_im, s.flags)
+            y = np.fft.fft(x, axis=0)
+            if s.tw_n:
+                m = l * twb
+                assert m.max() < s.tw_n
+                y = y * np.conj(self.tw2(s, m))
+            _store(dst, doff, s.dst_im, s.flags, y)
+        elif s.kind in (fa.STEP_COPY, fa.STEP_HERM_EXPAND):
+            K = s.aux_n
+            g = _grids([K] + dn)
+            k, idx = g[0], g[1:]
+            soff = np.zeros_like(k) + sbase
+            doff = np.zeros_like(k) + dbase
+            for i, gi in enumerate(idx):
+                soff = soff + gi * dis[i]
+                doff = doff + gi * dos[i]
+            if s.kind == fa.STEP_HERM_EXPAND:
+                half = K // 2
+                ks = np.where(k <= half, k, K - k)
+                v = _load(src, soff + ks * s.is_l, s.src_im, 0)
+                v = np.where(k > half, np.conj(v), v)
+                v = np.where((k == 0) | (2 * k == K), v.real + 0j, v)
+                _store(dst, doff + k * s.os_l, s.dst_im, s.flags, v)
+                return
+            ks = k
+            if s.flags & fa.F_PERM_SRC:
+                ks = self.table(s.table2)[k]
+            valid = k < s.aux_valid
+            kss = np.where(valid, ks, 0)
+            v = _load(src, soff + kss * s.is_l, s.src_im, s.flags)
+            v = np.where(valid, v, 0)
+            if s.flags & fa.F_MUL_TABLE:
+                v = v * self.table(s.table)[k]
+            if s.flags & fa.F_MUL_CONJ:
+                v = v * np.conj(self.table(s.table)[k])
+            kd = k
+            if s.flags & fa.F_PERM_DST:
+                kd = self.table(s.table2)[k]
+            _store(dst, doff + kd * s.os_l, s.dst_im, s.flags, v)
+        elif s.kind in (fa.STEP_R2C_POST, fa.STEP_C2R_PRE):
+            n = s.aux_n
+            h = n // 2
+            npair = h // 2 + 1
+            g = _grids([npair] + dn)
+            k, idx = g[0], g[1:]
+            soff = np.zeros_like(k) + sbase
+            doff = np.zeros_like(k) + dbase
+            for i, gi in enumerate(idx):
+                soff = soff + gi * dis[i]
+                doff = doff + gi * dos[i]
+            km = h - k
+            w = self.tw2(s, k)
+            if s.kind == fa.STEP_R2C_POST:
+                zk = _load(src, soff + k * s.is_l, s.src_im, 0)
+                zm = _load(src, soff + np.where(km == h, 0, km) * s.is_l, s.src_im, 0)
+                E = 0.5 * (zk + np.conj(zm))
+                O = -0.5j * (zk - np.conj(zm))
+                P = O * np.conj(w)
+                yk = E + P
+                ym = np.conj(E - P)
+                yk = np.where(k == 0, yk.real + 0j, yk)
+                ym = np.where(k == 0, ym.real + 0j, ym)
+                # mirrored element first so that k == h-k keeps Y[k]
+                _store(dst, doff + km * s.os_l, s.dst_im, s.flags, ym)
+                _store(dst, doff + k * s.os_l, s.dst_im, s.flags, yk)
+            else:
+                yk = _load(src, soff + k * s.is_l, s.src_im, 0)
+                ym = _load(src, soff + km * s.is_l, s.src_im, 0)
+                yk = np.where(k == 0, yk.real + 0j, yk)
+                ym = np.where(k == 0, ym.real + 0j, ym)
+                E = yk + np.conj(ym)
+                D = yk - np.conj(ym)
+                O = D * w
+                zk = E + 1j * O
+                zm = np.conj(E - 1j * O)
+                ok = (km != k) & (km != h)
+                # scatter mirrored entries where they exist
+                kmm = np.where(ok, km, k)
+                _store(dst, doff + kmm * s.os_l, s.dst_im, s.flags, np.where(ok, zm, zk))
+                _store(dst, doff + k * s.os_l, s.dst_im, s.flags, zk)
+        elif s.kind == fa.STEP_RADER_MUL:
+            pm1 = s.aux_n
+            nvec = int(np.prod(dn)) if dn else 1
+            work = bufs[s.src_buf]
+            x0b = bufs[s.aux_buf]
+            omega = self.table(s.table)
+            # destination offsets of Y[0], vectors numbered with dims[0] fastest
+            doffs = np.zeros(nvec, dtype=np.int64) + dbase
+            rest = np.arange(nvec, dtype=np.int64)
+            for i in range(len(dn)):
+                doffs += (rest % dn[i]) * dos[i]
+                rest //= dn[i]
+            for v in range(nvec):
+                a = s.src_base + 2 * v * pm1
+                A = work[a:a + 2 * pm1:2] + 1j * work[a + 1:a + 2 * pm1:2]
+                x0 = x0b[s.aux_base + 2 * v] + 1j * x0b[s.aux_base + 2 * v + 1]
+                P = A * omega
+                P[0] += x0
+                work[a:a + 2 * pm1:2] = P.real
+                work[a + 1:a + 2 * pm1:2] = P.imag
+                _store(dst, np.array([doffs[v]]), s.dst_im, s.flags, np.array([x0 + A[0]]))
+        else:
+            raise AssertionError("unknown step kind %d" % s.kind)
+
+
+def scratch_reals(plan):
+    return max(16, plan.workspace_bytes // 8 + 16)
+
+
+def run_plan_on_host(plan, inarr, outarr):
+    """Interpret `plan` on numpy arrays (float64 views of the user's buffers)."""
+    it = Interp(plan)
+    a = inarr.reshape(-1).view(np.float64)
+    b = a if outarr is inarr else outarr.reshape(-1).view(np.float64)
+    it.run(a, b, scratch_reals(plan))
