@@ -24,6 +24,8 @@ typedef long long i64;
 /* complex elements one workgroup tile holds (two LDS images of 16 B each) */
 #define FA_TILE_ELEMS 4096
 #define FA_LMAX_SINGLE 4096
+/* complex elements per LDS image: 160 KiB / (2 images * 16 B) */
+#define FA_LDS_ELEMS 5120
 
 enum { FA_C2C = 0, FA_R2C = 1, FA_C2R = 2 };
 

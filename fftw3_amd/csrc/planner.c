@@ -326,6 +326,8 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
     T = FA_TILE_ELEMS / L;
     if (T < 1) T = 1;
     if (T > s->dim_n[0]) T = s->dim_n[0];
+    /* the LDS row is padded to an odd width (T | 1): both images must fit 160 KiB */
+    while (T > 1 && L * (T | 1) > FA_LDS_ELEMS) --T;
     if (T < 1) T = 1;
     s->tile = (int)T;
     s->tw_n = tw_n;
