@@ -1,0 +1,340 @@
+"""GPU parity tests: every transform goes through the C ABI of
+libfftw3_amd.so onto device memory and is compared with the CPU oracle, the
+golden fixtures and -- at the BASELINE sizes where no stored answer exists --
+the reference verifier's properties (tests/verifier.py).  Tolerance: relative
+L-infinity 1e-10, the reference's own bound for double precision
+(fftw/libbench2/bench-main.c:70; north_star: "within 1e-10 rel-error")."""
+import os
+
+import numpy as np
+import pytest
+
+import fftw3_amd as fa
+import verifier
+from util import TOL, aerror, crand, oracle_c2r, oracle_dft, oracle_r2c, rrand
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert fa.device_count() > 0, "no HIP device: the GPU tier cannot run"
+    return torch, torch.device("cuda:0")
+
+
+def gpu_c2c(torch_dev, x, shape, b, sign=-1, inplace=False):
+    torch, dev = torch_dev
+    nn = int(np.prod(shape))
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    yd = xd if inplace else torch.zeros_like(xd)
+    p = fa.plan_many_dft(len(shape), list(shape), b, xd, None, 1, nn, yd, None, 1, nn, sign)
+    p.execute()
+    torch.cuda.synchronize()
+    return yd.cpu().numpy()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 16, 17, 25, 31, 32, 61, 64, 77,
+                               97, 100, 143, 1009, 1024, 1031, 4096, 5000, 15015, 17408, 65536,
+                               65537, 1 << 20])
+def test_c2c_1d_matches_oracle(torch_dev, n):
+    rng = np.random.default_rng(n)
+    for b in (1, 3):
+        for sign in (-1, 1):
+            x = crand(rng, b, n)
+            y = gpu_c2c(torch_dev, x, (n,), b, sign)
+            assert aerror(y, oracle_dft(x, (n,), b, sign).reshape(b, n)) < TOL
+    x = crand(rng, 2, n)
+    y = gpu_c2c(torch_dev, x, (n,), 2, -1, inplace=True)
+    assert aerror(y, oracle_dft(x, (n,), 2).reshape(2, n)) < TOL
+
+
+def test_sweep_1_to_100_and_pow2(torch_dev):
+    """the reference's size sweep (fftw/tests/check.pl:126-173), forward and backward"""
+    rng = np.random.default_rng(7)
+    for n in list(range(1, 101)) + [128, 256, 512, 2048]:
+        x = crand(rng, 2, n)
+        for sign in (-1, 1):
+            y = gpu_c2c(torch_dev, x, (n,), 2, sign)
+            assert aerror(y, oracle_dft(x, (n,), 2, sign).reshape(2, n)) < TOL, n
+
+
+def test_golden_fixtures(torch_dev):
+    torch, dev = torch_dev
+    z = np.load(os.path.join(GOLD, "c2c_1d.npz"))
+    for k in [f for f in z.files if f.startswith("n") and f.endswith("_in")]:
+        n = int(k[1:-3])
+        x = z[k].reshape(1, n)
+        assert aerror(gpu_c2c(torch_dev, x, (n,), 1, -1)[0], z["n%d_fwd" % n]) < TOL, n
+        assert aerror(gpu_c2c(torch_dev, x, (n,), 1, +1)[0], z["n%d_bwd" % n]) < TOL, n
+    for n in (4, 13, 64, 1024):
+        x = z["v3n%d_in" % n]
+        assert aerror(gpu_c2c(torch_dev, x, (n,), 3), z["v3n%d_fwd" % n]) < TOL
+        # interleaved vectors NvV: stride 3, dist 1
+        xi = torch.from_numpy(np.ascontiguousarray(x.T)).to(dev)
+        yi = torch.zeros_like(xi)
+        fa.plan_many_dft(1, [n], 3, xi, None, 3, 1, yi, None, 3, 1, fa.FORWARD).execute()
+        torch.cuda.synchronize()
+        assert aerror(yi.cpu().numpy().T, z["v3n%d_fwd" % n]) < TOL
+    z = np.load(os.path.join(GOLD, "r2c_1d.npz"))
+    for k in [f for f in z.files if f.endswith("_in")]:
+        n = int(k[1:-3])
+        xd = torch.from_numpy(z[k]).to(dev)
+        yd = torch.zeros(n // 2 + 1, dtype=torch.complex128, device=dev)
+        fa.plan_dft_r2c_1d(n, xd, yd).execute()
+        torch.cuda.synchronize()
+        assert aerror(yd.cpu().numpy(), z["n%d_out" % n]) < TOL, n
+        zd = torch.zeros(n, dtype=torch.float64, device=dev)
+        yin = torch.from_numpy(z["n%d_out" % n]).to(dev)
+        fa.plan_dft_c2r_1d(n, yin, zd).execute()
+        torch.cuda.synchronize()
+        assert aerror(zd.cpu().numpy(), z[k] * n) < TOL, n
+    z = np.load(os.path.join(GOLD, "nd.npz"))
+    for k in [f for f in z.files if f.startswith("c") and f.endswith("_in")]:
+        shape = tuple(int(s) for s in k[1:-3].split("x"))
+        y = gpu_c2c(torch_dev, z[k].reshape((1,) + shape), shape, 1)
+        assert aerror(y[0], z[k[:-3] + "_fwd"]) < TOL
+    for k in [f for f in z.files if f.startswith("r") and f.endswith("_in")]:
+        shape = tuple(int(s) for s in k[1:-3].split("x"))
+        xd = torch.from_numpy(z[k]).to(dev)
+        yd = torch.zeros((shape[0], shape[1] // 2 + 1), dtype=torch.complex128, device=dev)
+        fa.plan_dft_r2c_2d(shape[0], shape[1], xd, yd).execute()
+        torch.cuda.synchronize()
+        assert aerror(yd.cpu().numpy(), z[k[:-3] + "_out"]) < TOL
+
+
+@pytest.mark.parametrize("shape", [(4, 4), (8, 16), (16, 8), (13, 11), (64, 64), (3, 5, 7),
+                                   (600, 6), (5, 2048), (256, 256), (30, 30), (2, 3, 4, 5),
+                                   (1030, 4), (4096, 3)])
+def test_c2c_nd_matches_oracle(torch_dev, shape):
+    rng = np.random.default_rng(3)
+    for b in (1, 2):
+        for sign in (-1, 1):
+            x = crand(rng, b, *shape)
+            y = gpu_c2c(torch_dev, x, shape, b, sign)
+            assert aerror(y, oracle_dft(x, shape, b, sign).reshape(x.shape)) < TOL
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 8, 15, 16, 64, 128, 4096, 10000, 17, 97, 1009, 2018,
+                               1 << 15, 1 << 21])
+def test_r2c_c2r_1d(torch_dev, n):
+    torch, dev = torch_dev
+    rng = np.random.default_rng(n)
+    b = 2
+    x = rrand(rng, b, n)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.zeros((b, n // 2 + 1), dtype=torch.complex128, device=dev)
+    fa.plan_many_dft_r2c(1, [n], b, xd, None, 1, n, yd, None, 1, n // 2 + 1).execute()
+    torch.cuda.synchronize()
+    ref = oracle_r2c(x, (n,), b).reshape(b, n // 2 + 1)
+    y = yd.cpu().numpy()
+    assert aerror(y, ref) < TOL
+    assert np.all(y[:, 0].imag == 0) and (n % 2 or np.all(y[:, n // 2].imag == 0))
+    assert np.array_equal(xd.cpu().numpy(), x)                 # r2c preserves its input
+    yin = torch.from_numpy(ref).to(dev)
+    zd = torch.zeros((b, n), dtype=torch.float64, device=dev)
+    fa.plan_many_dft_c2r(1, [n], b, yin, None, 1, n // 2 + 1, zd, None, 1, n).execute()
+    torch.cuda.synchronize()
+    assert aerror(zd.cpu().numpy(), oracle_c2r(ref, (n,), b).reshape(b, n)) < TOL
+
+
+@pytest.mark.parametrize("shape", [(4, 4), (8, 16), (13, 11), (16, 9), (64, 64), (5, 6, 8), (128, 1024)])
+def test_r2c_c2r_nd(torch_dev, shape):
+    torch, dev = torch_dev
+    rng = np.random.default_rng(5)
+    nn, hs = int(np.prod(shape)), shape[:-1] + (shape[-1] // 2 + 1,)
+    hh = int(np.prod(hs))
+    x = rrand(rng, 2, *shape)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.zeros((2,) + hs, dtype=torch.complex128, device=dev)
+    fa.plan_many_dft_r2c(len(shape), list(shape), 2, xd, None, 1, nn, yd, None, 1, hh).execute()
+    torch.cuda.synchronize()
+    ref = oracle_r2c(x, shape, 2).reshape((2,) + hs)
+    assert aerror(yd.cpu().numpy(), ref) < TOL
+    yin = torch.from_numpy(ref).to(dev)
+    zd = torch.zeros((2,) + shape, dtype=torch.float64, device=dev)
+    fa.plan_many_dft_c2r(len(shape), list(shape), 2, yin, None, 1, hh, zd, None, 1, nn).execute()
+    torch.cuda.synchronize()
+    assert aerror(zd.cpu().numpy(), x * nn) < TOL
+    assert np.array_equal(yin.cpu().numpy(), ref)              # scratch keeps the input intact
+
+
+def test_layouts_inplace_embed_split_guru_newarray(torch_dev):
+    torch, dev = torch_dev
+    rng = np.random.default_rng(9)
+    # in-place padded r2c (fftw_rdft2_pad layout)
+    n, b = 1000, 3
+    pad = 2 * (n // 2 + 1)
+    x = rrand(rng, b, n)
+    buf = np.zeros((b, pad))
+    buf[:, :n] = x
+    bd = torch.from_numpy(buf).to(dev)
+    fa.plan_many_dft_r2c(1, [n], b, bd, None, 1, pad, bd, None, 1, pad // 2).execute()
+    torch.cuda.synchronize()
+    assert aerror(bd.cpu().numpy().view(complex), oracle_r2c(x, (n,), b).reshape(b, n // 2 + 1)) < TOL
+    # embedded sub-array, untouched surroundings
+    xe = crand(rng, 12, 20)
+    xd = torch.from_numpy(xe).to(dev)
+    yd = torch.full((10, 16), 7.0 + 0j, dtype=torch.complex128, device=dev)
+    fa.plan_many_dft(2, [6, 8], 1, xd, [12, 20], 1, 0, yd, [10, 16], 1, 0, fa.FORWARD).execute()
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    assert aerror(y[:6, :8], np.fft.fft2(xe[:6, :8])) < TOL
+    assert np.all(y[6:] == 7) and np.all(y[:, 8:] == 7)
+    # guru: strided transform dim, two loop dims
+    n, h0, h1 = 30, 3, 2
+    xg = crand(rng, h0, h1, n * 7)
+    xd = torch.from_numpy(xg).to(dev)
+    yd = torch.zeros((h0, h1, n), dtype=torch.complex128, device=dev)
+    fa.plan_guru64_dft([(n, 7, 1)], [(h0, h1 * n * 7, h1 * n), (h1, n * 7, n)], xd, yd,
+                       fa.FORWARD).execute()
+    torch.cuda.synchronize()
+    assert aerror(yd.cpu().numpy(), np.fft.fft(xg[:, :, ::7], axis=2)) < TOL
+    # split arrays
+    n = 960
+    planes = torch.from_numpy(rrand(rng, 2, n)).to(dev)
+    outp = torch.zeros_like(planes)
+    p = fa.plan_guru64_split_dft([(n, 1, 1)], [], planes[0], planes[1], outp[0], outp[1])
+    p.execute()
+    torch.cuda.synchronize()
+    pl = planes.cpu().numpy()
+    o = outp.cpu().numpy()
+    assert aerror(o[0] + 1j * o[1], np.fft.fft(pl[0] + 1j * pl[1])) < TOL
+    # new-array execute on other buffers (reference fftw_execute_dft, A.c:434-440)
+    n, b = 4096, 4
+    x1, x2 = crand(rng, b, n), crand(rng, b, n)
+    d1, d2 = torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev)
+    o1, o2 = torch.zeros_like(d1), torch.zeros_like(d2)
+    p = fa.plan_many_dft(1, [n], b, d1, None, 1, n, o1, None, 1, n, fa.FORWARD)
+    p.execute_dft(d2, o2)
+    torch.cuda.synchronize()
+    assert aerror(o2.cpu().numpy(), oracle_dft(x2, (n,), b).reshape(b, n)) < TOL
+    assert float(o1.abs().max()) == 0.0
+    # howmany == 0 executes nothing
+    fa.plan_many_dft(1, [n], 0, d1, None, 1, n, o1, None, 1, n, fa.FORWARD).execute()
+
+
+def test_host_arrays_are_staged(torch_dev):
+    """plain host pointers (numpy) take the PCIe staging path, incl. gaps in the output"""
+    rng = np.random.default_rng(2)
+    x = crand(rng, 2, 1000)
+    y = np.zeros_like(x)
+    fa.plan_many_dft(1, [1000], 2, x, None, 1, 1000, y, None, 1, 1000, fa.FORWARD).execute()
+    assert aerror(y, oracle_dft(x, (1000,), 2).reshape(2, 1000)) < TOL
+    xs = crand(rng, 64 * 3)
+    ys = np.full(64 * 2, 5.0 + 0j)
+    fa.plan_many_dft(1, [64], 1, xs, None, 3, 0, ys, None, 2, 0, fa.BACKWARD).execute()
+    assert aerror(ys[::2], np.fft.ifft(xs[::3]) * 64) < TOL
+    assert np.all(ys[1::2] == 5.0)
+    xi = x.copy()
+    fa.plan_many_dft(1, [1000], 2, xi, None, 1, 1000, xi, None, 1, 1000, fa.FORWARD).execute()
+    assert aerror(xi, y) < TOL
+    xr = rrand(rng, 500)
+    yr = np.zeros(251, dtype=complex)
+    fa.plan_dft_r2c_1d(500, xr, yr).execute()
+    assert aerror(yr, np.fft.rfft(xr)) < TOL
+
+
+def test_chunked_batches_and_ragged_tail(torch_dev):
+    torch, dev = torch_dev
+    rng = np.random.default_rng(4)
+    fa.set_chunk_bytes(1 << 20)
+    try:
+        n, b = 1 << 14, 11                     # 256 KiB per transform -> chunk 4, tail 3
+        x = crand(rng, b, n)
+        xd = torch.from_numpy(x).to(dev)
+        yd = torch.zeros_like(xd)
+        p = fa.plan_many_dft(1, [n], b, xd, None, 1, n, yd, None, 1, n, fa.FORWARD)
+        assert 1 <= p.chunk < b
+        p.execute()
+        torch.cuda.synchronize()
+        assert aerror(yd.cpu().numpy(), oracle_dft(x, (n,), b).reshape(b, n)) < TOL
+    finally:
+        fa.set_chunk_bytes(0)
+
+
+def _gpu_apply(torch_dev, shape, sign=-1):
+    torch, dev = torch_dev
+    cache = {}
+
+    def apply(x):
+        b = x.shape[0]
+        xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        yd = torch.empty_like(xd)
+        nn = int(np.prod(shape))
+        if b not in cache:
+            cache[b] = fa.plan_many_dft(len(shape), list(shape), b, xd, None, 1, nn, yd, None, 1,
+                                        nn, sign)
+        cache[b].execute_dft(xd, yd)
+        torch.cuda.synchronize()
+        return yd.cpu().numpy()
+    return apply
+
+
+@pytest.mark.parametrize("shape,vecn", [((1024,), 4), ((1 << 20,), 2), ((15015,), 2),
+                                        ((1031,), 2), ((65537,), 1), ((256, 256), 2),
+                                        ((4096, 4096), 1)])
+def test_reference_verifier_on_gpu(torch_dev, shape, vecn):
+    """impulse / linearity / shift battery of the reference (verify-lib.c) on the GPU path"""
+    rounds = 1 if int(np.prod(shape)) > (1 << 22) else 3
+    for sign in (-1, 1):
+        e = verifier.verify_c2c(_gpu_apply(torch_dev, shape, sign), shape, vecn=vecn, sign=sign,
+                                rounds=rounds)
+        assert e < TOL
+
+
+def test_mixed_radix_baseline_size_against_oracle(torch_dev):
+    """cfg4 unit: N = 3*5*7*11*13*2^10, one transform against the oracle"""
+    n = 3 * 5 * 7 * 11 * 13 * 1024
+    rng = np.random.default_rng(15)
+    x = crand(rng, 1, n)
+    y = gpu_c2c(torch_dev, x, (n,), 1)
+    assert aerror(y[0], oracle_dft(x, (n,))) < TOL
+
+
+def test_r2c_baseline_size_roundtrip(torch_dev):
+    """cfg3 unit: r2c N = 2^22 against the oracle, then c2r(r2c(x)) = N x"""
+    torch, dev = torch_dev
+    n, b = 1 << 22, 2
+    rng = np.random.default_rng(22)
+    x = rrand(rng, b, n)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.zeros((b, n // 2 + 1), dtype=torch.complex128, device=dev)
+    fa.plan_many_dft_r2c(1, [n], b, xd, None, 1, n, yd, None, 1, n // 2 + 1).execute()
+    torch.cuda.synchronize()
+    assert aerror(yd.cpu().numpy(), oracle_r2c(x, (n,), b).reshape(b, n // 2 + 1)) < TOL
+    zd = torch.zeros_like(xd)
+    fa.plan_many_dft_c2r(1, [n], b, yd, None, 1, n // 2 + 1, zd, None, 1, n).execute()
+    torch.cuda.synchronize()
+    assert aerror(zd.cpu().numpy(), x * n) < TOL
+
+
+def test_full_batch_known_answer_cfg2(torch_dev):
+    """BASELINE configs[1] at full size: N = 2^20, howmany = 4096 (64 GiB in, 64 GiB
+    out).  Row b holds an impulse (1+2i) at position s_b; its transform is the
+    closed form (1+2i) exp(-2 pi i s_b k / N), checked on device for every row."""
+    torch, dev = torch_dev
+    n, b = 1 << 20, 4096
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * (1 << 30):
+        pytest.skip("needs ~140 GiB of free HBM")
+    xd = torch.zeros((b, n), dtype=torch.complex128, device=dev)
+    yd = torch.empty_like(xd)
+    s = (torch.arange(b, device=dev, dtype=torch.int64) * 977 + 5) % n
+    xd[torch.arange(b, device=dev), s] = 1 + 2j
+    p = fa.plan_many_dft(1, [n], b, xd, None, 1, n, yd, None, 1, n, fa.FORWARD)
+    p.execute()
+    torch.cuda.synchronize()
+    k = torch.arange(n, device=dev, dtype=torch.int64)
+    worst = 0.0
+    for r0 in range(0, b, 64):
+        rows = slice(r0, r0 + 64)
+        m = (s[rows, None] * k[None, :]) % n
+        ang = m.to(torch.float64) * (-2.0 * np.pi / n)
+        want = torch.polar(torch.ones_like(ang), ang) * (1 + 2j)
+        worst = max(worst, float((yd[rows] - want).abs().max()))
+        del m, ang, want
+    assert worst / 2.0 < TOL
+    del xd, yd
+    torch.cuda.empty_cache()

