@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the FFT executor on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2c|r2c|mixed|2d]
+
+A "step" is one fftw_execute of the whole batch of synthetic input that is
+already resident in HBM.  At N=1 the default workload is BASELINE.json
+configs[1]: 1-D complex double N = 2^20, howmany = 4096 (fftw_plan_many_dft),
+forward, out of place.  The metric is the reference's own
+(fftw/libbench2/mflops.c:21-28): GFLOPS = 5 N log2 N * howmany / t.
+
+With --gpus N > 1 the driver launches one process per GPU
+(torch.distributed.run); whole batch elements are sharded across ranks, every
+rank transforms the same per-GPU batch (weak scaling) and nothing is exchanged
+inside the timed region.  `--gather` adds the RCCL all-gather of the outputs
+(reported separately: it is xGMI-bound).
+
+Rank 0 prints ONE JSON line.  It carries `roofline` for the dominant kernel
+(HIP events around every launch, on the stream the kernels run on) and, at
+N=1, `cpu_baseline`: the CPU oracle timed on one host core on a bounded sample
+of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def workload(name, batch_override):
+    """(rank dims, howmany, kind, flops per transform, algorithmic bytes per transform)"""
+    if name == "c2c":
+        n = [1 << 20]
+        b = 4096
+        kind = "c2c"
+    elif name == "r2c":
+        n = [1 << 22]
+        b = 1024
+        kind = "r2c"
+    elif name == "mixed":
+        n = [3 * 5 * 7 * 11 * 13 * 1024]
+        b = 256           # 2048 does not fit one GPU (504 GB per array): sub-batch of 256
+        kind = "c2c"
+    elif name == "2d":
+        n = [4096, 4096]
+        b = 64            # per-GPU share of 512 images on 8 GPUs
+        kind = "c2c"
+    else:
+        raise SystemExit("unknown workload " + name)
+    if batch_override:
+        b = batch_override
+    size = 1
+    for v in n:
+        size *= v
+    if kind == "c2c":
+        flops = 5.0 * size * math.log2(size)
+        abytes = 32.0 * size
+    else:
+        flops = 2.5 * size * math.log2(size)
+        abytes = 8.0 * size + 16.0 * (size // n[-1]) * (n[-1] // 2 + 1)
+    return n, b, kind, flops, abytes
+
+
+def cpu_baseline(n, kind, flops_per_transform, target_seconds=12.0):
+    """the oracle (a port, one core) on a bounded sample of the same workload"""
+    import numpy as np
+    from util import oracle_dft, oracle_r2c
+    rng = np.random.default_rng(1)
+    size = int(np.prod(n))
+    if kind == "c2c":
+        x = (rng.random(size) - 0.5) + 1j * (rng.random(size) - 0.5)
+        run = lambda: oracle_dft(x, tuple(n), 1)
+    else:
+        x = rng.random(size) - 0.5
+        run = lambda: oracle_r2c(x, tuple(n), 1)
+    run()                                   # builds the oracle's twiddle cache
+    t0 = time.perf_counter()
+    run()
+    one = time.perf_counter() - t0
+    reps = max(1, min(256, int(target_seconds / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    dt = time.perf_counter() - t0
+    return {
+        "value": flops_per_transform * reps / dt / 1e9,
+        "unit": "GFLOPS",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d transforms of n=%s (oracle/fftw_oracle.c, 1 thread, %.1f s)" % (
+            reps, "x".join(str(v) for v in n), dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2c")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU howmany override")
+    ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of outputs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import fftw3_amd as fa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    if fa.device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device: the executor has no CPU path")
+
+    n, b, kind, flops1, abytes1 = workload(args.workload, args.batch)
+    size = 1
+    for v in n:
+        size *= v
+    # shrink the batch if this GPU cannot hold input + output + scratch
+    free, _ = torch.cuda.mem_get_info()
+    per = (32 if kind == "c2c" else 8 + 17) * size
+    while b > 1 and b * per + (1 << 30) > free:
+        b //= 2
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)
+    if kind == "c2c":
+        x = torch.empty((b, size), dtype=torch.complex128, device=dev)
+        xr = torch.view_as_real(x)
+        step_rows = max(1, (1 << 28) // size)
+        for r0 in range(0, b, step_rows):        # uniform [-0.5, 0.5), filled in slabs
+            sl = xr[r0:r0 + step_rows]
+            sl.copy_(torch.rand(sl.shape, dtype=torch.float64, device=dev, generator=gen) - 0.5)
+        y = torch.empty_like(x)
+        plan = fa.plan_many_dft(len(n), n, b, x, None, 1, size, y, None, 1, size, fa.FORWARD,
+                                fa.ESTIMATE)
+    else:
+        hs = size // n[-1] * (n[-1] // 2 + 1)
+        x = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
+        y = torch.empty((b, hs), dtype=torch.complex128, device=dev)
+        plan = fa.plan_many_dft_r2c(len(n), n, b, x, None, 1, size, y, None, 1, hs, fa.ESTIMATE)
+    plan.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.execute()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.execute()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_transforms = b * world * args.steps
+    gflops = flops1 * total_transforms / dt / 1e9
+    alg_gbs = abytes1 * total_transforms / dt / 1e9
+
+    # ---- roofline of the dominant kernel: HIP events around every launch
+    prof = plan.execute_profiled()
+    torch.cuda.synchronize()
+    roof = None
+    if prof:
+        dom = max(prof, key=lambda t: t[1])
+        st, ms, launches = dom
+        avg_ms = ms / max(1, launches)
+        units = min(plan.chunk, plan.batch)           # transforms one launch processes
+        # a pass reads every element of its chunk once and writes it once
+        bytes_per_launch = abytes1 * units
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roof = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "step%d kind=%d L=%d variant=%d" % (prof.index(dom), st.kind, st.L, st.variant),
+            "avg_launch_ms": avg_ms, "launches_per_step": launches,
+            "alg_bytes_per_launch": bytes_per_launch,
+            "whole_transform_GBs": alg_gbs / world, "whole_transform_frac": alg_gbs / world / HBM_PEAK_GBS,
+            "steps_ms": [round(t[1], 4) for t in prof],
+        }
+
+    gather = None
+    if args.gather and dist is not None:
+        from fftw3_amd.parallel import ShardedManyDft  # noqa: F401  (same collective as the helper)
+        gb = min(b, max(1, (int(free * 0.35) // (16 * size)) // world))
+        src = y[:gb].contiguous()
+        dst = torch.empty((world * gb, y.shape[1]), dtype=y.dtype, device=dev)
+        barrier()
+        t0 = time.perf_counter()
+        dist.all_gather_into_tensor(torch.view_as_real(dst), torch.view_as_real(src))
+        barrier()
+        tg = time.perf_counter() - t0
+        gather = {"seconds": tg, "bytes_received_per_rank": (world - 1) * src.numel() * 16,
+                  "GBs_per_rank": (world - 1) * src.numel() * 16 / tg / 1e9}
+
+    if rank == 0:
+        out = {
+            "metric": "GFLOPS (5N*log2N) + achieved HBM GB/s, 1D complex double N=2^20 batch=4096"
+            if args.workload == "c2c" else "GFLOPS (reference mflops formula), workload " + args.workload,
+            "value": gflops, "unit": "GFLOPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s n=%s howmany=%d per GPU, forward, out-of-place, FFTW_ESTIMATE" % (
+                kind, "x".join(str(v) for v in n), b),
+                "algorithmic_GBs": alg_gbs, "parallelism": "batch-sharded x%d" % world,
+                "plan": plan.sprint().replace("\n", " ")},
+            "roofline": roof,
+        }
+        if gather:
+            out["all_gather"] = gather
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, kind, flops1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -133,6 +133,7 @@ _sig("fftw_amd_plan_get_step", C.c_int, _vp, C.c_int, C.POINTER(StepDesc))
 _sig("fftw_amd_plan_chunk", C.c_longlong, _vp)
 _sig("fftw_amd_plan_batch", C.c_longlong, _vp)
 _sig("fftw_amd_plan_table", C.c_longlong, _vp, C.c_int, C.POINTER(C.c_double), C.c_longlong)
+_sig("fftw_amd_execute_profiled", C.c_int, _vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int)
 _sig("fftw_amd_cexp", None, C.c_longlong, C.c_longlong, C.POINTER(C.c_double))
 _sig("fftw_amd_find_generator", C.c_longlong, C.c_longlong)
 _sig("fftw_amd_power_mod", C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong)
@@ -214,6 +215,16 @@ class Plan(object):
 
     def sync(self):
         lib.fftw_amd_plan_sync(self.handle)
+
+    def execute_profiled(self):
+        """one execution with HIP events around every launch:
+        [(step, total_ms, launches), ...]"""
+        self._need_device()
+        st = self.steps()
+        ms = (C.c_double * max(1, len(st)))()
+        cnt = (C.c_longlong * max(1, len(st)))()
+        k = lib.fftw_amd_execute_profiled(self.handle, ms, cnt, len(st))
+        return [(st[i], ms[i], cnt[i]) for i in range(max(0, k))]
 
     def sprint(self):
         p = lib.fftw_sprint_plan(self.handle)

@@ -23,6 +23,10 @@ void  fa_hip_memcpy_h2d(void *dst, const void *src, size_t nbytes, void *stream)
 void  fa_hip_memcpy_d2h(void *dst, const void *src, size_t nbytes, void *stream);
 void  fa_hip_memset(void *dst, int v, size_t nbytes, void *stream);
 void  fa_hip_stream_sync(void *stream);
+void *fa_hip_event_create(void);
+void  fa_hip_event_record(void *ev, void *stream);
+float fa_hip_event_elapsed_ms(void *start, void *stop);   /* both must have completed */
+void  fa_hip_event_destroy(void *ev);
 
 /* Launch one step.  bufs[i] is the device base pointer of buffer id i, tables[i]
    the device pointer of table id i.  (chunk_start, chunk_n) select the slice

@@ -466,6 +466,21 @@ extern "C" void fa_hip_stream_sync(void *stream) {
     FA_CHECK(hipStreamSynchronize((hipStream_t)stream));
 }
 
+extern "C" void *fa_hip_event_create(void) {
+    hipEvent_t e;
+    FA_CHECK(hipEventCreate(&e));
+    return (void *)e;
+}
+extern "C" void fa_hip_event_record(void *ev, void *stream) {
+    FA_CHECK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+}
+extern "C" float fa_hip_event_elapsed_ms(void *a, void *b) {
+    float ms = 0.f;
+    FA_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b));
+    return ms;
+}
+extern "C" void fa_hip_event_destroy(void *ev) { FA_CHECK(hipEventDestroy((hipEvent_t)ev)); }
+
 static inline i64 iabs64(i64 v) { return v < 0 ? -v : v; }
 
 static void grid_for(i64 total, dim3 *grid) {

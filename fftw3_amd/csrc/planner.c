@@ -1069,6 +1069,10 @@ static double *stage_buf(double **slot, size_t *have, size_t need) {
     return *slot;
 }
 
+/* per-step HIP-event timing of one execution: set by fftw_amd_execute_profiled */
+static double *g_prof_ms = NULL;
+static long long *g_prof_launches = NULL;
+
 void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
     double *bufs[FA_MAXBUF];
     void *tabs[FA_MAXTAB];
@@ -1119,14 +1123,35 @@ void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
     for (i = 2; i < p->nbufs; ++i) bufs[i] = p->dbuf[i];
     for (i = 0; i < p->ntabs; ++i) tabs[i] = p->tabs[i].dev;
 
-    for (cs = 0; cs < p->batch; cs += p->chunk) {
-        i64 cn = p->batch - cs < p->chunk ? p->batch - cs : p->chunk;
-        for (i = 0; i < p->nsteps; ++i) {
-            fftw_amd_step_desc d = p->steps[i];
-            /* split-array callers may pass different re/im distances per call */
-            if (d.src_buf == 0 && p->type != FA_R2C && d.src_im == p->in_im) d.src_im = in_im;
-            if (d.dst_buf == 1 && p->type != FA_C2R && d.dst_im == p->out_im) d.dst_im = out_im;
-            if (fa_hip_launch_step(&d, bufs, tabs, cs, cn, p->stream)) abort();
+    {
+        i64 nchunks = (p->batch + p->chunk - 1) / p->chunk, ev = 0;
+        void **events = NULL;
+        if (g_prof_ms) events = (void **)malloc(sizeof(void *) * (size_t)(2 * nchunks * p->nsteps));
+        for (cs = 0; cs < p->batch; cs += p->chunk) {
+            i64 cn = p->batch - cs < p->chunk ? p->batch - cs : p->chunk;
+            for (i = 0; i < p->nsteps; ++i) {
+                fftw_amd_step_desc d = p->steps[i];
+                /* split-array callers may pass different re/im distances per call */
+                if (d.src_buf == 0 && p->type != FA_R2C && d.src_im == p->in_im) d.src_im = in_im;
+                if (d.dst_buf == 1 && p->type != FA_C2R && d.dst_im == p->out_im) d.dst_im = out_im;
+                if (events) { events[ev] = fa_hip_event_create(); fa_hip_event_record(events[ev++], p->stream); }
+                if (fa_hip_launch_step(&d, bufs, tabs, cs, cn, p->stream)) abort();
+                if (events) { events[ev] = fa_hip_event_create(); fa_hip_event_record(events[ev++], p->stream); }
+            }
+        }
+        if (events) {
+            i64 c;
+            fa_hip_stream_sync(p->stream);
+            ev = 0;
+            for (c = 0; c < nchunks; ++c)
+                for (i = 0; i < p->nsteps; ++i) {
+                    g_prof_ms[i] += (double)fa_hip_event_elapsed_ms(events[ev], events[ev + 1]);
+                    g_prof_launches[i] += 1;
+                    fa_hip_event_destroy(events[ev]);
+                    fa_hip_event_destroy(events[ev + 1]);
+                    ev += 2;
+                }
+            free(events);
         }
     }
 
@@ -1138,6 +1163,21 @@ void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
         fa_hip_memcpy_d2h(ro + lo, dout + lo, bytes, p->stream);
     }
     if (in_host || out_host) fa_hip_stream_sync(p->stream);
+}
+
+/* One execution on the plan's own arrays with a HIP event pair around every
+   launch (on the stream the kernels run on).  ms[i] / launches[i] accumulate
+   the time and the number of launches of step i.  Returns the step count. */
+int fftw_amd_execute_profiled(fftw_plan p, double *ms, long long *launches, int cap) {
+    int i;
+    if (!p || cap < p->nsteps) return -1;
+    for (i = 0; i < p->nsteps; ++i) { ms[i] = 0.0; launches[i] = 0; }
+    g_prof_ms = ms;
+    g_prof_launches = launches;
+    fa_run(p, p->ri, p->ii, p->ro, p->io);
+    g_prof_ms = NULL;
+    g_prof_launches = NULL;
+    return p->nsteps;
 }
 
 /* ------------------------------------------------------------- printing */

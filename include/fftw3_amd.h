@@ -108,6 +108,12 @@ long long fftw_amd_plan_batch(const fftw_plan p);
    doubles (writes at most cap doubles). */
 long long fftw_amd_plan_table(const fftw_plan p, int id, double *dst, long long cap);
 
+/* Execute once on the plan's own arrays with a HIP event pair around every
+   kernel launch, on the stream the kernels run on.  ms[i] receives the summed
+   duration of step i over all chunks, launches[i] how often it was launched.
+   Returns the number of steps, -1 if cap is too small. */
+int fftw_amd_execute_profiled(fftw_plan p, double *ms, long long *launches, int cap);
+
 /* Host-side numerics exported for the tests (no device needed). */
 void fftw_amd_cexp(long long m, long long n, double out[2]);  /* (cos, sin)(2 pi m / n) */
 long long fftw_amd_find_generator(long long p);
