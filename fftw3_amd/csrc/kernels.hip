@@ -71,6 +71,10 @@ FA_DEV cplx tw2(const cplx *lo, const cplx *hi, int shift, i64 m) {
     return c_mul(a, b);
 }
 
+static inline i64 iabs64(i64 v) { return v < 0 ? -v : v; }
+
+#include "pass1024.hpp"
+
 /* ------------------------------------------------------------------------ */
 /* generic LDS pass kernel (runtime radices)                                 */
 /* ------------------------------------------------------------------------ */
@@ -167,6 +171,7 @@ pass_generic_kernel(const PassArgs a) {
     const int Tcur = (int)((a.dn[0] - t0 < a.T) ? (a.dn[0] - t0) : a.T);
     const int L = a.L, ld = a.ld;
     const int total = L * Tcur;
+    const bool tw_in = a.tw_n && (a.flags & FFTW_AMD_F_TW_IN);
 
     /* ---- load tile into LDS, coalesced along whichever index is contiguous */
     for (int e = tid; e < total; e += nth) {
@@ -174,7 +179,12 @@ pass_generic_kernel(const PassArgs a) {
         if (a.in_t_fast) { l = e / Tcur; t = e - l * Tcur; }
         else             { t = e / L;    l = e - t * L; }
         i64 addr = soff + (i64)l * a.is_l + (t0 + t) * a.dis[0];
-        A[l * ld + t] = load_elem<VIN>(a.src, addr, a.src_im, a.flags);
+        cplx v = load_elem<VIN>(a.src, addr, a.src_im, a.flags);
+        if (tw_in) {
+            i64 m = (i64)l * (twb + (t0 + t) * a.dtw[0]);
+            v = c_mulc(v, tw2(a.tw_lo, a.tw_hi, a.tw_shift, m));
+        }
+        A[l * ld + t] = v;
     }
     __syncthreads();
 
@@ -205,7 +215,7 @@ pass_generic_kernel(const PassArgs a) {
         if (a.out_t_fast) { l = e / Tcur; t = e - l * Tcur; }
         else              { t = e / L;    l = e - t * L; }
         cplx v = A[l * ld + t];
-        if (a.tw_n) {
+        if (a.tw_n && !tw_in) {
             i64 m = (i64)l * (twb + (t0 + t) * a.dtw[0]);
             v = c_mulc(v, tw2(a.tw_lo, a.tw_hi, a.tw_shift, m));
         }
@@ -481,7 +491,6 @@ extern "C" float fa_hip_event_elapsed_ms(void *a, void *b) {
 }
 extern "C" void fa_hip_event_destroy(void *ev) { FA_CHECK(hipEventDestroy((hipEvent_t)ev)); }
 
-static inline i64 iabs64(i64 v) { return v < 0 ? -v : v; }
 
 static void grid_for(i64 total, dim3 *grid) {
     i64 blocks = (total + 255) / 256;
@@ -503,9 +512,74 @@ static void launch_pass_variant(const PassArgs &pa, dim3 grid, size_t lds, hipSt
     hipLaunchKernelGGL((pass_generic_kernel<VIN, VOUT>), grid, dim3(256), lds, st, pa);
 }
 
+template <bool IN_T, bool OUT_T, int HAS_TW>
+static void launch_p1024_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    const size_t lds = FA_P1024_LDS_DOUBLES * sizeof(double);
+    if (!attr_done) {
+        FA_CHECK(hipFuncSetAttribute((const void *)pass1024_kernel<IN_T, OUT_T, HAS_TW>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pass1024_kernel<IN_T, OUT_T, HAS_TW>), grid, dim3(256), lds, st, pa);
+}
+
+/* the register-resident 1024-point pass; returns 1 if the step does not
+   qualify (caller falls through to the generic kernel) */
+static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                        i64 cs, i64 cn, hipStream_t st) {
+    P1024Args pa;
+    int bd = d->batch_dim;
+    i64 sbase = d->src_base, dbase = d->dst_base;
+    if (d->L != 1024 || d->src_im != 1 || d->dst_im != 1 ||
+        (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
+        return 1;
+    for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+        pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+        pa.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+        pa.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+        pa.dtw[i] = (i < d->ndims) ? d->dim_tw[i] : 0;
+    }
+    if (bd >= 0) {
+        sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+        dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+        pa.dn[bd] = cn;
+    }
+    pa.src = bufs[d->src_buf] + sbase;
+    pa.dst = bufs[d->dst_buf] + dbase;
+    pa.is_l = d->is_l;
+    pa.os_l = d->os_l;
+    if (((uintptr_t)pa.src % 16) || ((uintptr_t)pa.dst % 16) || (pa.is_l % 2) || (pa.os_l % 2)) return 1;
+    for (int i = 0; i < d->ndims; ++i)
+        if ((pa.dis[i] % 2) || (pa.dos[i] % 2)) return 1;
+    pa.w1024 = (const cplx *)tables[d->table];
+    pa.tw_shift = d->tw_shift;
+    pa.tw_lo = d->tw_n ? (const cplx *)tables[d->tw_lo] : NULL;
+    pa.tw_hi = d->tw_n ? (const cplx *)tables[d->tw_hi] : NULL;
+    pa.ndims = d->ndims;
+    pa.flags = d->flags;
+    pa.ntiles = (pa.dn[0] + 7) / 8;
+    i64 nblocks = pa.ntiles;
+    for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
+    if (nblocks <= 0) return 0;
+    if (nblocks > 0x7fffffffLL) return 1;
+    dim3 grid((unsigned)nblocks, 1, 1);
+    bool in_t = pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l);
+    bool out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);
+    int tw = d->tw_n == 0 ? 0 : ((d->flags & FFTW_AMD_F_TW_IN) ? 2 : 1);
+#define FA_P1024_CASE(I, O, W) if (in_t == I && out_t == O && tw == W) { launch_p1024_variant<I, O, W>(pa, grid, st); return 0; }
+    FA_P1024_CASE(true, true, 0)  FA_P1024_CASE(true, true, 1)  FA_P1024_CASE(true, true, 2)
+    FA_P1024_CASE(false, true, 0) FA_P1024_CASE(false, true, 1) FA_P1024_CASE(false, true, 2)
+    FA_P1024_CASE(true, false, 0) FA_P1024_CASE(true, false, 1) FA_P1024_CASE(true, false, 2)
+    FA_P1024_CASE(false, false, 0) FA_P1024_CASE(false, false, 1) FA_P1024_CASE(false, false, 2)
+#undef FA_P1024_CASE
+    return 1;
+}
+
 static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                        i64 cs, i64 cn, hipStream_t st) {
     PassArgs pa;
+    if (d->variant == FFTW_AMD_K_P1024 && launch_p1024(d, bufs, tables, cs, cn, st) == 0) return 0;
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
     for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
@@ -535,7 +609,8 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
     for (int i = 0; i < FFTW_AMD_MAX_RADICES; ++i) pa.rad[i] = (i < d->nradices) ? d->radices[i] : 1;
     pa.ndims = d->ndims;
     pa.T = d->tile;
-    pa.ld = (d->tile > 1) ? (d->tile | 1) : 1;
+    while (pa.T > 1 && (i64)d->L * (pa.T | 1) > 5120) --pa.T;   /* tile of a tuned variant may not fit here */
+    pa.ld = (pa.T > 1) ? (pa.T | 1) : 1;
     pa.flags = d->flags;
     pa.ntiles = (pa.dn[0] + pa.T - 1) / pa.T;
     /* a stride-0 dim cannot be the coalescing index */

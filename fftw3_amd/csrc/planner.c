@@ -330,6 +330,11 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
     while (T > 1 && L * (T | 1) > FA_LDS_ELEMS) --T;
     if (T < 1) T = 1;
     s->tile = (int)T;
+    if (L == 1024 && src.im == 1 && dst.im == 1 &&
+        !(flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT)) && !getenv("FFTW_AMD_NO_TUNED")) {
+        s->variant = FFTW_AMD_K_P1024;      /* register-resident radix-32x32, 8 sequences per tile */
+        s->tile = 8;
+    }
     s->tw_n = tw_n;
     if (tw_n) tab_tw2(p, tw_n, &s->tw_lo, &s->tw_hi, &s->tw_shift);
     {
@@ -441,7 +446,10 @@ static void emit_ct(plan *p, const fa_axis *ax, const i64 *lens, int k) {
                 d[nd].tw = 0; d[nd].is_batch = (j == ax->batch_loop); ++nd;
             }
             flags = ax->flags_in & (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_REAL_IN);
-            emit_pass(p, ax->src, tmp, lens[0], M[0] * ax->is, M[0] * ts, d, nd, ax->n, flags);
+            /* two passes: the twiddle w_n^(k_0 j) is applied by the last pass on
+               its input (index j along the row, k_0 = which row) */
+            emit_pass(p, ax->src, tmp, lens[0], M[0] * ax->is, M[0] * ts, d, nd,
+                      k == 2 ? 0 : ax->n, flags);
         } else if (i < k - 1) {
             /* scratch -> scratch, in place */
             d[nd].n = M[i]; d[nd].is = ts; d[nd].os = ts; d[nd].tw = 1; d[nd].is_batch = 0; ++nd;
@@ -458,14 +466,16 @@ static void emit_ct(plan *p, const fa_axis *ax, const i64 *lens, int k) {
             /* scratch -> destination, digits reversed into natural order */
             for (j = 0; j < k - 1; ++j) {
                 d[nd].n = lens[j]; d[nd].is = M[j] * ts; d[nd].os = Pf[j] * ax->os;
-                d[nd].tw = 0; d[nd].is_batch = 0; ++nd;
+                d[nd].tw = (k == 2) ? 1 : 0; d[nd].is_batch = 0; ++nd;
             }
             for (j = 0; j < ax->nloops; ++j) {
                 d[nd].n = ax->loops[j].n; d[nd].is = lts[j]; d[nd].os = ax->loops[j].os;
                 d[nd].tw = 0; d[nd].is_batch = (j == ax->batch_loop); ++nd;
             }
             flags = ax->flags_out & (FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_REAL_OUT);
-            emit_pass(p, tmp, ax->dst, lens[k - 1], ts, Pf[k - 1] * ax->os, d, nd, 0, flags);
+            if (k == 2) flags |= FFTW_AMD_F_TW_IN;
+            emit_pass(p, tmp, ax->dst, lens[k - 1], ts, Pf[k - 1] * ax->os, d, nd,
+                      k == 2 ? ax->n : 0, flags);
         }
     }
     buf_release(p, tbuf);

@@ -84,7 +84,8 @@ enum {
 };
 
 enum {
-    FFTW_AMD_K_GENERIC = 0      /* runtime-radix LDS kernel */
+    FFTW_AMD_K_GENERIC = 0,     /* runtime-radix LDS kernel */
+    FFTW_AMD_K_P1024 = 1        /* register-resident radix-32x32 kernel, tile of 8 */
 };
 
 enum {
@@ -96,7 +97,8 @@ enum {
     FFTW_AMD_F_MUL_CONJ  = 1 << 5, /* copy: multiply by conj(table[k]) */
     FFTW_AMD_F_PERM_SRC  = 1 << 6, /* copy: source index through permutation */
     FFTW_AMD_F_PERM_DST  = 1 << 7, /* copy: destination index through permutation */
-    FFTW_AMD_F_CONJ_OUT  = 1 << 8  /* conjugate on store */
+    FFTW_AMD_F_CONJ_OUT  = 1 << 8, /* conjugate on store */
+    FFTW_AMD_F_TW_IN     = 1 << 9  /* pass: the twiddle multiplies the INPUT element (l, q) instead of the output */
 };
 
 int fftw_amd_plan_num_steps(const fftw_plan p);

@@ -123,8 +123,12 @@ class Interp(object):
             rad = [s.radices[i] for i in range(s.nradices)]
             assert int(np.prod(rad)) == L if rad else L == 1
             x = _load(src, soff, s.src_im, s.flags)
+            if s.tw_n and (s.flags & fa.F_TW_IN):
+                m = l * twb
+                assert m.max() < s.tw_n
+                x = x * np.conj(self.tw2(s, m))
             y = np.fft.fft(x, axis=0)
-            if s.tw_n:
+            if s.tw_n and not (s.flags & fa.F_TW_IN):
                 m = l * twb
                 assert m.max() < s.tw_n
                 y = y * np.conj(self.tw2(s, m))

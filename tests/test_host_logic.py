@@ -42,7 +42,10 @@ def test_planner_decompositions():
     x = np.zeros(1 << 20, dtype=complex)
     p = fa.plan_dft_1d(1 << 20, x, x.copy(), fa.FORWARD)
     s = p.steps()
-    assert [d.L for d in s] == [1024, 1024] and s[0].tw_n == 1 << 20 and s[1].tw_n == 0
+    assert [d.L for d in s] == [1024, 1024]
+    # two passes: the inter-pass twiddle rides on the input of the second one
+    assert s[0].tw_n == 0 and s[1].tw_n == 1 << 20 and (s[1].flags & fa.F_TW_IN)
+    assert [d.variant for d in s] == [1, 1]          # both run the register-resident kernel
     assert fa.factor_passes(3 * 5 * 7 * 11 * 13 * 1024) and \
         int(np.prod(fa.factor_passes(3 * 5 * 7 * 11 * 13 * 1024))) == 15375360
     assert fa.factor_passes(1024) == [1024]
