@@ -27,6 +27,9 @@ void *fa_hip_event_create(void);
 void  fa_hip_event_record(void *ev, void *stream);
 float fa_hip_event_elapsed_ms(void *start, void *stop);   /* both must have completed */
 void  fa_hip_event_destroy(void *ev);
+void *fa_hip_stream_create(void);                   /* non-blocking stream */
+void  fa_hip_stream_destroy(void *stream);
+void  fa_hip_stream_wait_event(void *stream, void *ev);
 
 /* Launch one step.  bufs[i] is the device base pointer of buffer id i, tables[i]
    the device pointer of table id i.  (chunk_start, chunk_n) select the slice

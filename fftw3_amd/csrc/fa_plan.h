@@ -99,6 +99,13 @@ struct fftw_plan_s {
 
     void *stream;
     int dev_ready;
+
+    /* chunk pipeline: stage A (steps [0, split)) of chunk c+1 overlaps stage B
+       (steps [split, nsteps)) of chunk c on a second stream; each chunk works
+       in scratch slot c % nslots */
+    int nslots, split;
+    void *pstream[2];
+    void *ev_a[4], *ev_b[4], *ev_begin, *ev_end[2];
     int failed;
 
     /* staging for plain host pointers */

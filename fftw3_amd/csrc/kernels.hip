@@ -490,6 +490,15 @@ extern "C" float fa_hip_event_elapsed_ms(void *a, void *b) {
     return ms;
 }
 extern "C" void fa_hip_event_destroy(void *ev) { FA_CHECK(hipEventDestroy((hipEvent_t)ev)); }
+extern "C" void *fa_hip_stream_create(void) {
+    hipStream_t s;
+    FA_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return (void *)s;
+}
+extern "C" void fa_hip_stream_destroy(void *s) { FA_CHECK(hipStreamDestroy((hipStream_t)s)); }
+extern "C" void fa_hip_stream_wait_event(void *s, void *ev) {
+    FA_CHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0));
+}
 
 
 static void grid_for(i64 total, dim3 *grid) {

@@ -25,6 +25,7 @@ typedef struct fftw_plan_s plan;
 
 static size_t g_chunk_bytes = (size_t)64 << 20;
 static i64 g_lmax_multi = 1024;
+static int g_pipeline = 1;
 
 void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : ((size_t)64 << 20); }
 
@@ -40,6 +41,8 @@ plan *fa_plan_new(void) {
     p->in_im = p->out_im = 1;
     e = getenv("FFTW_AMD_CHUNK_BYTES");
     if (e && atoll(e) > 0) g_chunk_bytes = (size_t)atoll(e);
+    e = getenv("FFTW_AMD_PIPELINE");
+    if (e) g_pipeline = atoi(e);
     e = getenv("FFTW_AMD_LMAX_MULTI");
     if (e && atoll(e) >= 16) g_lmax_multi = atoll(e);
     return p;
@@ -69,6 +72,14 @@ void fa_plan_free(plan *p) {
         for (i = 2; i < p->nbufs; ++i) fa_hip_free(p->dbuf[i]);
         fa_hip_free(p->stage_in);
         fa_hip_free(p->stage_out);
+        if (p->pstream[0]) {
+            for (i = 0; i < 4; ++i) { fa_hip_event_destroy(p->ev_a[i]); fa_hip_event_destroy(p->ev_b[i]); }
+            fa_hip_event_destroy(p->ev_begin);
+            fa_hip_event_destroy(p->ev_end[0]);
+            fa_hip_event_destroy(p->ev_end[1]);
+            fa_hip_stream_destroy(p->pstream[0]);
+            fa_hip_stream_destroy(p->pstream[1]);
+        }
     }
     for (i = 0; i < p->ntabs; ++i) free(p->tabs[i].host);
     free(p->steps);
@@ -1064,8 +1075,26 @@ int fa_device_init(plan *p) {
             fa_plan_free(q);
         }
     }
+    /* chunk pipeline: worth it when there are several chunks of >= 2 steps */
+    p->nslots = 1;
+    if (p->chunk > 0 && p->nsteps >= 2 && (p->batch + p->chunk - 1) / p->chunk >= 3 &&
+        !p->single_chunk && g_pipeline) {
+        i64 per = 0;
+        for (i = 2; i < p->nbufs; ++i) per += p->buf_reals[i];
+        if (per > 0 && (size_t)per * sizeof(double) * 3 <= ((size_t)1 << 31)) {
+            p->nslots = 3;
+            p->split = p->nsteps / 2;
+            p->pstream[0] = fa_hip_stream_create();
+            p->pstream[1] = fa_hip_stream_create();
+            for (i = 0; i < 4; ++i) { p->ev_a[i] = fa_hip_event_create(); p->ev_b[i] = fa_hip_event_create(); }
+            p->ev_begin = fa_hip_event_create();
+            p->ev_end[0] = fa_hip_event_create();
+            p->ev_end[1] = fa_hip_event_create();
+        }
+    }
     for (i = 2; i < p->nbufs; ++i)
-        if (!p->dbuf[i]) p->dbuf[i] = (double *)fa_hip_malloc((size_t)p->buf_reals[i] * sizeof(double));
+        if (!p->dbuf[i])
+            p->dbuf[i] = (double *)fa_hip_malloc((size_t)p->buf_reals[i] * sizeof(double) * (size_t)p->nslots);
     p->dev_ready = 1;
     return 0;
 }
@@ -1134,23 +1163,50 @@ void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
     for (i = 0; i < p->ntabs; ++i) tabs[i] = p->tabs[i].dev;
 
     {
-        i64 nchunks = (p->batch + p->chunk - 1) / p->chunk, ev = 0;
+        i64 nchunks = (p->batch + p->chunk - 1) / p->chunk, ev = 0, c = 0;
         void **events = NULL;
+        const int pipe = p->nslots > 1;
         if (g_prof_ms) events = (void **)malloc(sizeof(void *) * (size_t)(2 * nchunks * p->nsteps));
-        for (cs = 0; cs < p->batch; cs += p->chunk) {
+        if (pipe) {
+            /* the side streams start after everything already queued on the caller's stream */
+            fa_hip_event_record(p->ev_begin, p->stream);
+            fa_hip_stream_wait_event(p->pstream[0], p->ev_begin);
+            fa_hip_stream_wait_event(p->pstream[1], p->ev_begin);
+        }
+        for (cs = 0; cs < p->batch; cs += p->chunk, ++c) {
             i64 cn = p->batch - cs < p->chunk ? p->batch - cs : p->chunk;
+            double *sb[FA_MAXBUF];
+            int slot = pipe ? (int)(c % p->nslots) : 0;
+            sb[0] = bufs[0];
+            sb[1] = bufs[1];
+            for (i = 2; i < p->nbufs; ++i) sb[i] = bufs[i] + (i64)slot * p->buf_reals[i];
             for (i = 0; i < p->nsteps; ++i) {
                 fftw_amd_step_desc d = p->steps[i];
+                void *st = p->stream;
+                if (pipe) {
+                    st = p->pstream[i < p->split ? 0 : 1];
+                    /* stage A reuses a slot only after stage B of its previous user is done */
+                    if (i == 0 && c >= p->nslots) fa_hip_stream_wait_event(st, p->ev_b[slot]);
+                    if (i == p->split) fa_hip_stream_wait_event(st, p->ev_a[slot]);
+                }
                 /* split-array callers may pass different re/im distances per call */
                 if (d.src_buf == 0 && p->type != FA_R2C && d.src_im == p->in_im) d.src_im = in_im;
                 if (d.dst_buf == 1 && p->type != FA_C2R && d.dst_im == p->out_im) d.dst_im = out_im;
-                if (events) { events[ev] = fa_hip_event_create(); fa_hip_event_record(events[ev++], p->stream); }
-                if (fa_hip_launch_step(&d, bufs, tabs, cs, cn, p->stream)) abort();
-                if (events) { events[ev] = fa_hip_event_create(); fa_hip_event_record(events[ev++], p->stream); }
+                if (events) { events[ev] = fa_hip_event_create(); fa_hip_event_record(events[ev++], st); }
+                if (fa_hip_launch_step(&d, sb, tabs, cs, cn, st)) abort();
+                if (events) { events[ev] = fa_hip_event_create(); fa_hip_event_record(events[ev++], st); }
+                if (pipe && i == p->split - 1) fa_hip_event_record(p->ev_a[slot], st);
+                if (pipe && i == p->nsteps - 1) fa_hip_event_record(p->ev_b[slot], st);
             }
         }
+        if (pipe) {
+            /* the caller's stream continues after both side streams have drained */
+            fa_hip_event_record(p->ev_end[0], p->pstream[0]);
+            fa_hip_event_record(p->ev_end[1], p->pstream[1]);
+            fa_hip_stream_wait_event(p->stream, p->ev_end[0]);
+            fa_hip_stream_wait_event(p->stream, p->ev_end[1]);
+        }
         if (events) {
-            i64 c;
             fa_hip_stream_sync(p->stream);
             ev = 0;
             for (c = 0; c < nchunks; ++c)

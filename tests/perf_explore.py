@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 n = 1 << 20
 b = int(os.environ.get("B", "512"))
 x = torch.randn(b, n, dtype=torch.complex128, device=dev); y = torch.empty_like(x)
-for mib in [int(v) for v in os.environ.get("CHUNKS", "64,128,256,512,1024,4096").split(",")]:
+for mib in [int(v) for v in os.environ.get("CHUNKS", "16,32,64,128,256,1024").split(",")]:
     fa.set_chunk_bytes(mib << 20)
     p = fa.plan_many_dft(1, [n], b, x, None, 1, n, y, None, 1, n, -1)
     p.execute(); torch.cuda.synchronize()
