@@ -74,6 +74,7 @@ FA_DEV cplx tw2(const cplx *lo, const cplx *hi, int shift, i64 m) {
 static inline i64 iabs64(i64 v) { return v < 0 ? -v : v; }
 
 #include "pass1024.hpp"
+#include "stream1024.hpp"
 
 /* ------------------------------------------------------------------------ */
 /* generic LDS pass kernel (runtime radices)                                 */
@@ -567,6 +568,7 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
     pa.tw_hi = d->tw_n ? (const cplx *)tables[d->tw_hi] : NULL;
     pa.ndims = d->ndims;
     pa.flags = d->flags;
+    { const char *e = getenv("FFTW_AMD_DBG"); if (e) pa.flags |= atoi(e) << 20; }
     pa.ntiles = (pa.dn[0] + 7) / 8;
     i64 nblocks = pa.ntiles;
     for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
@@ -576,6 +578,40 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
     bool in_t = pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l);
     bool out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);
     int tw = d->tw_n == 0 ? 0 : ((d->flags & FFTW_AMD_F_TW_IN) ? 2 : 1);
+    {
+        /* long tile lists: the persistent software-pipelined form (one workgroup per CU) */
+        static int stream_mode = -1, ncu = 0;
+        if (stream_mode < 0) {
+            const char *e = getenv("FFTW_AMD_STREAM");
+            hipDeviceProp_t prop;
+            int dev = 0;
+            stream_mode = e ? atoi(e) : 0;   /* opt-in: measured slower than the 2-workgroup form */
+            FA_CHECK(hipGetDevice(&dev));
+            FA_CHECK(hipGetDeviceProperties(&prop, dev));
+            ncu = prop.multiProcessorCount;
+        }
+        if (stream_mode && nblocks >= 4 * (i64)ncu) {
+            S1024Args sa;
+            for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+                sa.ps.dn[i] = pa.dn[i]; sa.ps.dis[i] = pa.dis[i]; sa.ps.dos[i] = pa.dos[i]; sa.ps.dtw[i] = pa.dtw[i];
+            }
+            sa.ps.src = pa.src; sa.ps.dst = pa.dst; sa.ps.is_l = pa.is_l; sa.ps.os_l = pa.os_l;
+            sa.ps.ntiles0 = pa.ntiles; sa.ps.total = nblocks; sa.ps.ndims = pa.ndims; sa.ps.flags = pa.flags;
+            sa.w1024 = pa.w1024; sa.tw_lo = pa.tw_lo; sa.tw_hi = pa.tw_hi; sa.tw_shift = pa.tw_shift;
+            dim3 sgrid((unsigned)ncu, 1, 1);
+            const size_t lds = FA_S1024_LDS_CPLX * sizeof(cplx);
+#define FA_S1024_CASE(I, O, W) if (in_t == I && out_t == O && tw == W) { \
+                static bool done = false; \
+                if (!done) { FA_CHECK(hipFuncSetAttribute((const void *)stream1024_kernel<I, O, W>, \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; } \
+                hipLaunchKernelGGL((stream1024_kernel<I, O, W>), sgrid, dim3(256), lds, st, sa); return 0; }
+            FA_S1024_CASE(true, true, 0)  FA_S1024_CASE(true, true, 1)  FA_S1024_CASE(true, true, 2)
+            FA_S1024_CASE(false, true, 0) FA_S1024_CASE(false, true, 1) FA_S1024_CASE(false, true, 2)
+            FA_S1024_CASE(true, false, 0) FA_S1024_CASE(true, false, 1) FA_S1024_CASE(true, false, 2)
+            FA_S1024_CASE(false, false, 0) FA_S1024_CASE(false, false, 1) FA_S1024_CASE(false, false, 2)
+#undef FA_S1024_CASE
+        }
+    }
 #define FA_P1024_CASE(I, O, W) if (in_t == I && out_t == O && tw == W) { launch_p1024_variant<I, O, W>(pa, grid, st); return 0; }
     FA_P1024_CASE(true, true, 0)  FA_P1024_CASE(true, true, 1)  FA_P1024_CASE(true, true, 2)
     FA_P1024_CASE(false, true, 0) FA_P1024_CASE(false, true, 1) FA_P1024_CASE(false, true, 2)

@@ -164,7 +164,11 @@ pass1024_kernel(const P1024Args a) {
     const int ti = IN_T ? (tid & 7) : (tid >> 5);
     const int ai = IN_T ? (tid >> 3) : (tid & 31);
     cplx x[32];
-    {
+    const bool dbg_nocompute = (a.flags >> 20) & 1, dbg_noload = (a.flags >> 21) & 1, dbg_nostore = (a.flags >> 22) & 1;
+    if (dbg_noload) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) x[i] = c_make(1.0 + tid + i, 2.0 - i);
+    } else {
         const double *p = a.src + soff + (i64)ai * a.is_l + (t0 + ti) * a.dis[0];
         const i64 step = 32 * a.is_l;
         if (ti < Tcur) {
@@ -180,6 +184,13 @@ pass1024_kernel(const P1024Args a) {
         }
     }
 
+    const int to = OUT_T ? (tid & 7) : (tid >> 5);
+    const int dq = OUT_T ? (tid >> 3) : (tid & 31);
+    cplx y[32];
+    if (dbg_nocompute) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) y[q] = x[q];
+    } else {
     /* ---- inter-pass twiddle on the input: conj(w_N^((ai + 32 i) q)) */
     if (HAS_TW == 2) {
         const i64 q = twb + (t0 + ti) * a.dtw[0];
@@ -200,9 +211,6 @@ pass1024_kernel(const P1024Args a) {
     }
 
     /* ---- exchange through LDS, one real plane at a time */
-    const int to = OUT_T ? (tid & 7) : (tid >> 5);
-    const int dq = OUT_T ? (tid >> 3) : (tid & 31);
-    cplx y[32];
 #pragma unroll
     for (int d = 0; d < 32; ++d) plane[lds_index<IN_T, OUT_T>(d, ai, ti)] = x[slot32(d)].x;
     __syncthreads();
@@ -227,9 +235,10 @@ pass1024_kernel(const P1024Args a) {
         for (int s = 0; s < 5; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * 32) << s);
         TwTree<4, 0, true, true>::run(y, pw, base);
     }
+    }   /* !dbg_nocompute */
 
     /* ---- store */
-    if (to < Tcur) {
+    if (to < Tcur && !(dbg_nostore && y[3].x != 12345.678)) {
         double *p = a.dst + doff + (i64)dq * a.os_l + (t0 + to) * a.dos[0];
         const i64 step = 32 * a.os_l;
         const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;

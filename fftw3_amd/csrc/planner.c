@@ -23,11 +23,11 @@
 
 typedef struct fftw_plan_s plan;
 
-static size_t g_chunk_bytes = (size_t)64 << 20;
+static size_t g_chunk_bytes = (size_t)256 << 20;
 static i64 g_lmax_multi = 1024;
 static int g_pipeline = 1;
 
-void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : ((size_t)64 << 20); }
+void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : ((size_t)256 << 20); }
 
 static i64 iabs(i64 v) { return v < 0 ? -v : v; }
 
