@@ -75,6 +75,7 @@ static inline i64 iabs64(i64 v) { return v < 0 ? -v : v; }
 
 #include "pass1024.hpp"
 #include "stream1024.hpp"
+#include "fused1024.hpp"
 
 /* ------------------------------------------------------------------------ */
 /* generic LDS pass kernel (runtime radices)                                 */
@@ -568,7 +569,6 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
     pa.tw_hi = d->tw_n ? (const cplx *)tables[d->tw_hi] : NULL;
     pa.ndims = d->ndims;
     pa.flags = d->flags;
-    { const char *e = getenv("FFTW_AMD_DBG"); if (e) pa.flags |= atoi(e) << 20; }
     pa.ntiles = (pa.dn[0] + 7) / 8;
     i64 nblocks = pa.ntiles;
     for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
@@ -830,4 +830,41 @@ extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bu
         fprintf(stderr, "fftw3_amd: unknown step kind %d\n", d->kind);
         return -1;
     }
+}
+
+extern "C" int fa_hip_launch_fused1024(const double *in, double *out, double *scratch, int nslots, int lag,
+                                       long long in_bs, long long out_bs, long long batch, int flags,
+                                       const void *w1024, const void *tw_lo, const void *tw_hi, int tw_shift,
+                                       int *ctrl, void *stream) {
+    static int ncu = 0;
+    static bool attr_done = false;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = FA_P1024_LDS_DOUBLES * sizeof(double);
+    if (((uintptr_t)in % 16) || ((uintptr_t)out % 16) || (in_bs % 2) || (out_bs % 2)) return 1;
+    if (!ncu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        FA_CHECK(hipGetDevice(&dev));
+        FA_CHECK(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount;
+    }
+    if (!attr_done) {
+        FA_CHECK(hipFuncSetAttribute((const void *)fused1024_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    Fused1024Args a;
+    a.in = in; a.out = out; a.scratch = scratch;
+    a.in_bs = in_bs; a.out_bs = out_bs; a.batch = batch;
+    a.nslots = nslots; a.lag = lag; a.nunits = batch + lag;
+    a.done1 = ctrl; a.done2 = ctrl + batch;
+    /* the 8-byte ticket stays aligned: ctrl is 16-byte aligned and 2*batch ints are a multiple of 8 bytes */
+    a.ticket = (unsigned long long *)(ctrl + 2 * batch);
+    a.error = ctrl + 2 * batch + 2;
+    a.w1024 = (const cplx *)w1024; a.tw_lo = (const cplx *)tw_lo; a.tw_hi = (const cplx *)tw_hi;
+    a.tw_shift = tw_shift; a.flags = flags;
+    { const char *e = getenv("FFTW_AMD_FUSED_DBG"); if (e) a.flags |= atoi(e) << 24; }
+    FA_CHECK(hipMemsetAsync(ctrl, 0, sizeof(int) * (size_t)(2 * batch + 16), st));
+    hipLaunchKernelGGL(fused1024_kernel, dim3(2 * ncu), dim3(256), lds, st, a);
+    return 0;
 }

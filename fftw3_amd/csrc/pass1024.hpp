@@ -126,74 +126,60 @@ template <bool IN_T, bool OUT_T> FA_DEV int lds_index(int d, int a, int t) {
 
 #define FA_P1024_LDS_DOUBLES 8448
 
-struct P1024Args {
+/* one tile = 8 sequences of 1024; pointers already address the tile origin */
+struct P1024Tile {
     const double *src;
     double *dst;
-    i64 is_l, os_l;
-    i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS], dtw[FFTW_AMD_MAX_DIMS];
+    i64 is_l, os_l;       /* stride of the transform index, in doubles */
+    i64 dis0, dos0;       /* stride between the 8 sequences */
+    i64 dtw0, q0;         /* twiddle position of sequence t: q0 + t * dtw0 */
     const cplx *w1024;
     const cplx *tw_lo;
     const cplx *tw_hi;
-    i64 ntiles;
     int tw_shift;
-    int ndims, flags;
+    int Tcur;             /* sequences present in this tile (<= 8) */
+    int flags;
 };
 
-/* HAS_TW: 0 none, 1 inter-pass twiddle on the output, 2 on the input */
-template <bool IN_T, bool OUT_T, int HAS_TW>
-__global__ void __launch_bounds__(256, 2)
-pass1024_kernel(const P1024Args a) {
-    extern __shared__ __attribute__((aligned(16))) double plane[];
+/* HAS_TW: 0 none, 1 inter-pass twiddle on the output, 2 on the input.
+   `plane` is FA_P1024_LDS_DOUBLES doubles of LDS.  All 256 work-items call. */
+typedef unsigned int fa_u32x4 __attribute__((ext_vector_type(4)));
 
-    const int tid = threadIdx.x;
-    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
-    i64 tile = blk % a.ntiles;
-    i64 rest = blk / a.ntiles;
-    i64 soff = 0, doff = 0, twb = 0;
-    for (int d = 1; d < a.ndims; ++d) {
-        i64 idx = rest % a.dn[d];
-        rest /= a.dn[d];
-        soff += idx * a.dis[d];
-        doff += idx * a.dos[d];
-        twb += idx * a.dtw[d];
-    }
-    const i64 t0 = tile * 8;
-    const int Tcur = (int)((a.dn[0] - t0 < 8) ? (a.dn[0] - t0) : 8);
+/* ST_SC1: the tile is handed to another workgroup inside the launch, so its
+   stores are write-through (sc1) buffer stores (guide section 6 G16, form R1) */
+/* hooks let a persistent caller slip independent scalar work (next ticket,
+   dependency poll) under the tile's memory latency */
+struct P1024NoHook {
+    FA_DEV void after_loads() {}
+    FA_DEV void mid() {}
+};
 
+template <bool IN_T, bool OUT_T, int HAS_TW, bool ST_SC1, class Hook>
+FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid, Hook &hook) {
     /* ---- load: item (ai, ti) owns l = ai + 32 i */
     const int ti = IN_T ? (tid & 7) : (tid >> 5);
     const int ai = IN_T ? (tid >> 3) : (tid & 31);
     cplx x[32];
-    const bool dbg_nocompute = (a.flags >> 20) & 1, dbg_noload = (a.flags >> 21) & 1, dbg_nostore = (a.flags >> 22) & 1;
-    if (dbg_noload) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) x[i] = c_make(1.0 + tid + i, 2.0 - i);
-    } else {
-        const double *p = a.src + soff + (i64)ai * a.is_l + (t0 + ti) * a.dis[0];
+    {
+        const double *p = a.src + (i64)ai * a.is_l + (i64)ti * a.dis0;
         const i64 step = 32 * a.is_l;
-        if (ti < Tcur) {
+        if (ti < a.Tcur) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) x[i] = *reinterpret_cast<const cplx *>(p + i * step);
         } else {
 #pragma unroll
             for (int i = 0; i < 32; ++i) x[i] = c_make(0.0, 0.0);
         }
+        hook.after_loads();
         if (a.flags & FFTW_AMD_F_SWAP_IN) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) { double s = x[i].x; x[i].x = x[i].y; x[i].y = s; }
         }
     }
 
-    const int to = OUT_T ? (tid & 7) : (tid >> 5);
-    const int dq = OUT_T ? (tid >> 3) : (tid & 31);
-    cplx y[32];
-    if (dbg_nocompute) {
-#pragma unroll
-        for (int q = 0; q < 32; ++q) y[q] = x[q];
-    } else {
     /* ---- inter-pass twiddle on the input: conj(w_N^((ai + 32 i) q)) */
     if (HAS_TW == 2) {
-        const i64 q = twb + (t0 + ti) * a.dtw[0];
+        const i64 q = a.q0 + (i64)ti * a.dtw0;
         cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * ai);
         cplx pw[5];
 #pragma unroll
@@ -211,6 +197,9 @@ pass1024_kernel(const P1024Args a) {
     }
 
     /* ---- exchange through LDS, one real plane at a time */
+    const int to = OUT_T ? (tid & 7) : (tid >> 5);
+    const int dq = OUT_T ? (tid >> 3) : (tid & 31);
+    cplx y[32];
 #pragma unroll
     for (int d = 0; d < 32; ++d) plane[lds_index<IN_T, OUT_T>(d, ai, ti)] = x[slot32(d)].x;
     __syncthreads();
@@ -223,23 +212,38 @@ pass1024_kernel(const P1024Args a) {
 #pragma unroll
     for (int q = 0; q < 32; ++q) y[q].y = plane[lds_index<IN_T, OUT_T>(dq, q, to)];
 
+    hook.mid();
+
     /* ---- second radix-32 butterfly over a: X[dq + 32 c] in y[slot32(c)] */
     bfly32(y);
 
     /* ---- inter-pass twiddle conj(w_N^((dq + 32 c) q)), q = position of this sequence */
     if (HAS_TW == 1) {
-        const i64 q = twb + (t0 + to) * a.dtw[0];
+        const i64 q = a.q0 + (i64)to * a.dtw0;
         cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * dq);
         cplx pw[5];
 #pragma unroll
         for (int s = 0; s < 5; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * 32) << s);
         TwTree<4, 0, true, true>::run(y, pw, base);
     }
-    }   /* !dbg_nocompute */
 
     /* ---- store */
-    if (to < Tcur && !(dbg_nostore && y[3].x != 12345.678)) {
-        double *p = a.dst + doff + (i64)dq * a.os_l + (t0 + to) * a.dos[0];
+    if (ST_SC1) {
+        /* wave-uniform descriptor over the tile's destination; per-lane byte offsets */
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, 0x7fffffff, 0x00020000);
+        const int off0 = (int)(((i64)dq * a.os_l + (i64)to * a.dos0) * 8);
+        const int step = (int)(32 * a.os_l * 8);
+        if (to < a.Tcur) {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                cplx v = y[slot32(c)];
+                fa_u32x4 w;
+                __builtin_memcpy(&w, &v, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, off0 + c * step, 0, 16);
+            }
+        }
+    } else if (to < a.Tcur) {
+        double *p = a.dst + (i64)dq * a.os_l + (i64)to * a.dos0;
         const i64 step = 32 * a.os_l;
         const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
 #pragma unroll
@@ -249,6 +253,53 @@ pass1024_kernel(const P1024Args a) {
             *reinterpret_cast<cplx *>(p + c * step) = v;
         }
     }
+}
+
+template <bool IN_T, bool OUT_T, int HAS_TW, bool ST_SC1 = false>
+FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid) {
+    P1024NoHook h;
+    p1024_tile<IN_T, OUT_T, HAS_TW, ST_SC1, P1024NoHook>(a, plane, tid, h);
+}
+
+struct P1024Args {
+    const double *src;
+    double *dst;
+    i64 is_l, os_l;
+    i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS], dtw[FFTW_AMD_MAX_DIMS];
+    const cplx *w1024;
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    i64 ntiles;
+    int tw_shift;
+    int ndims, flags;
+};
+
+template <bool IN_T, bool OUT_T, int HAS_TW>
+__global__ void __launch_bounds__(256, 2)
+pass1024_kernel(const P1024Args a) {
+    extern __shared__ __attribute__((aligned(16))) double plane[];
+    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
+    i64 tile = blk % a.ntiles;
+    i64 rest = blk / a.ntiles;
+    i64 soff = 0, doff = 0, twb = 0;
+    for (int d = 1; d < a.ndims; ++d) {
+        i64 idx = rest % a.dn[d];
+        rest /= a.dn[d];
+        soff += idx * a.dis[d];
+        doff += idx * a.dos[d];
+        twb += idx * a.dtw[d];
+    }
+    const i64 t0 = tile * 8;
+    P1024Tile t;
+    t.src = a.src + soff + t0 * a.dis[0];
+    t.dst = a.dst + doff + t0 * a.dos[0];
+    t.is_l = a.is_l; t.os_l = a.os_l;
+    t.dis0 = a.dis[0]; t.dos0 = a.dos[0];
+    t.dtw0 = a.dtw[0]; t.q0 = twb + t0 * a.dtw[0];
+    t.w1024 = a.w1024; t.tw_lo = a.tw_lo; t.tw_hi = a.tw_hi; t.tw_shift = a.tw_shift;
+    t.Tcur = (int)((a.dn[0] - t0 < 8) ? (a.dn[0] - t0) : 8);
+    t.flags = a.flags;
+    p1024_tile<IN_T, OUT_T, HAS_TW>(t, plane, threadIdx.x);
 }
 
 #endif /* FA_PASS1024_HPP */

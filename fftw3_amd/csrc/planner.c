@@ -26,6 +26,7 @@ typedef struct fftw_plan_s plan;
 static size_t g_chunk_bytes = (size_t)256 << 20;
 static i64 g_lmax_multi = 1024;
 static int g_pipeline = 1;
+static int g_fused = 0, g_fused_lag = 5, g_fused_slots = 10;   /* opt-in: FFTW_AMD_FUSED=1 */
 
 void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : ((size_t)256 << 20); }
 
@@ -41,6 +42,12 @@ plan *fa_plan_new(void) {
     p->in_im = p->out_im = 1;
     e = getenv("FFTW_AMD_CHUNK_BYTES");
     if (e && atoll(e) > 0) g_chunk_bytes = (size_t)atoll(e);
+    e = getenv("FFTW_AMD_FUSED");
+    if (e) g_fused = atoi(e);
+    e = getenv("FFTW_AMD_FUSED_SLOTS");
+    if (e && atoi(e) >= 2) g_fused_slots = atoi(e);
+    e = getenv("FFTW_AMD_FUSED_LAG");
+    if (e && atoi(e) >= 1) g_fused_lag = atoi(e);
     e = getenv("FFTW_AMD_PIPELINE");
     if (e) g_pipeline = atoi(e);
     e = getenv("FFTW_AMD_LMAX_MULTI");
@@ -72,6 +79,9 @@ void fa_plan_free(plan *p) {
         for (i = 2; i < p->nbufs; ++i) fa_hip_free(p->dbuf[i]);
         fa_hip_free(p->stage_in);
         fa_hip_free(p->stage_out);
+        fa_hip_free(p->fused_scratch);
+        fa_hip_free(p->fused_ctrl);
+        if (p->fused_err_host) fa_hip_host_free(p->fused_err_host);
         if (p->pstream[0]) {
             for (i = 0; i < 4; ++i) { fa_hip_event_destroy(p->ev_a[i]); fa_hip_event_destroy(p->ev_b[i]); }
             fa_hip_event_destroy(p->ev_begin);
@@ -1075,6 +1085,20 @@ int fa_device_init(plan *p) {
             fa_plan_free(q);
         }
     }
+    /* batched contiguous n = 2^20: both passes in one persistent launch */
+    if (g_fused && p->type == FA_C2C && p->rank == 1 && p->dims[0].n == ((i64)1 << 20) &&
+        p->dims[0].is == 2 && p->dims[0].os == 2 && p->hrank == 1 && p->nsteps == 2 &&
+        p->in_im == 1 && p->out_im == 1 && p->batch >= 8 && p->batch < ((i64)1 << 28) &&
+        p->steps[0].variant == FFTW_AMD_K_P1024 && p->steps[1].variant == FFTW_AMD_K_P1024 &&
+        (p->hdims[0].is % 2) == 0 && (p->hdims[0].os % 2) == 0) {
+        p->fused = 1;
+        p->fused_lag = g_fused_lag;
+        p->fused_slots = g_fused_slots > g_fused_lag ? g_fused_slots : g_fused_lag + 3;
+        p->fused_scratch = (double *)fa_hip_malloc((size_t)p->fused_slots * ((size_t)1 << 20) * 16);
+        p->fused_ctrl = (int *)fa_hip_malloc(sizeof(int) * (size_t)(2 * p->batch + 16));
+        p->fused_err_host = (int *)fa_hip_host_malloc(sizeof(int) * 4);
+        if (p->fused_err_host) p->fused_err_host[0] = 0;
+    }
     /* chunk pipeline: worth it when there are several chunks of >= 2 steps */
     p->nslots = 1;
     if (p->chunk > 0 && p->nsteps >= 2 && (p->batch + p->chunk - 1) / p->chunk >= 3 &&
@@ -1162,6 +1186,49 @@ void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
     for (i = 2; i < p->nbufs; ++i) bufs[i] = p->dbuf[i];
     for (i = 0; i < p->ntabs; ++i) tabs[i] = p->tabs[i].dev;
 
+    if (p->fused_err_host && p->fused_err_host[0]) {
+        fprintf(stderr, "fftw3_amd: fused kernel reported a synchronisation timeout (%d)\n", p->fused_err_host[0]);
+        abort();
+    }
+    if (p->fused && fa_hip_is_device_ptr(ri) && fa_hip_is_device_ptr(ro) && ii == ri + 1 && io == ro + 1) {
+        const fftw_amd_step_desc *s1 = &p->steps[1];
+        void *e0 = NULL, *e1 = NULL;
+        int flags = (p->sign > 0) ? (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT) : 0;
+        if (g_prof_ms) { e0 = fa_hip_event_create(); e1 = fa_hip_event_create(); fa_hip_event_record(e0, p->stream); }
+        if (fa_hip_launch_fused1024(bufs[0], bufs[1], p->fused_scratch, p->fused_slots, p->fused_lag,
+                                    p->hdims[0].is, p->hdims[0].os, p->batch, flags,
+                                    tabs[s1->table], tabs[s1->tw_lo], tabs[s1->tw_hi], s1->tw_shift,
+                                    p->fused_ctrl, p->stream) == 0) {
+            if (p->fused_err_host)
+                fa_hip_memcpy_d2h(p->fused_err_host, p->fused_ctrl + 2 * p->batch + 2, sizeof(int), p->stream);
+            if (getenv("FFTW_AMD_FUSED_DEBUG")) {
+                int *h = (int *)malloc(sizeof(int) * (size_t)(2 * p->batch + 16));
+                i64 k, lo1 = 1 << 30, hi1 = 0, lo2 = 1 << 30, hi2 = 0;
+                fa_hip_memcpy_d2h(h, p->fused_ctrl, sizeof(int) * (size_t)(2 * p->batch + 16), p->stream);
+                fa_hip_stream_sync(p->stream);
+                for (k = 0; k < p->batch; ++k) {
+                    if (h[k] < lo1) lo1 = h[k];
+                    if (h[k] > hi1) hi1 = h[k];
+                    if (h[p->batch + k] < lo2) lo2 = h[p->batch + k];
+                    if (h[p->batch + k] > hi2) hi2 = h[p->batch + k];
+                }
+                fprintf(stderr, "fused: ticket=%d error=%d done1=[%lld,%lld] done2=[%lld,%lld] "
+                        "slot-waits blocked=%d spins=%d  pass2-waits blocked=%d spins=%d\n",
+                        h[2 * p->batch], h[2 * p->batch + 2], lo1, hi1, lo2, hi2,
+                        h[2 * p->batch + 4], h[2 * p->batch + 5], h[2 * p->batch + 6], h[2 * p->batch + 7]);
+                free(h);
+            }
+            if (g_prof_ms) {
+                fa_hip_event_record(e1, p->stream);
+                fa_hip_stream_sync(p->stream);
+                g_prof_ms[0] += (double)fa_hip_event_elapsed_ms(e0, e1);
+                g_prof_launches[0] += 1;
+                fa_hip_event_destroy(e0);
+                fa_hip_event_destroy(e1);
+            }
+            return;
+        }
+    }
     {
         i64 nchunks = (p->batch + p->chunk - 1) / p->chunk, ev = 0, c = 0;
         void **events = NULL;
