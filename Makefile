@@ -9,14 +9,14 @@ LIBDIR := fftw3_amd/lib
 CFLAGS := -O2 -fPIC -std=gnu99 -Wall -Wextra -Iinclude -I$(CSRC)
 HIPFLAGS := -O3 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -std=c++17 -Wall
 
-OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/hostmath.o $(CSRC)/kernels.o
+OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/hostmath.o $(CSRC)/kernels.o $(CSRC)/kernels_rr.o
 
 all: $(LIBDIR)/libfftw3_amd.so
 
 $(CSRC)/%.o: $(CSRC)/%.c $(CSRC)/fa_plan.h $(CSRC)/fa_hip.h include/fftw3.h include/fftw3_amd.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(CSRC)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_amd.h $(wildcard $(CSRC)/*.hpp)
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_amd.h $(wildcard $(CSRC)/*.hpp)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libfftw3_amd.so: $(OBJS)

@@ -14,64 +14,7 @@
  *   r2c_post / c2r_pre   <- ct_hc2c_direct_apply A.c:5831-5845 with the
  *       hc2cfdft / hc2cbdft codelets, plus the DC/Nyquist zeroing A.c:7155.
  */
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-
-#define FA_DEV __device__ __forceinline__
-#include "butterflies.h"
-#include "fa_hip.h"
-
-typedef long long i64;
-
-#define FA_CHECK(call)                                                              \
-    do {                                                                            \
-        hipError_t e_ = (call);                                                     \
-        if (e_ != hipSuccess) {                                                     \
-            fprintf(stderr, "fftw3_amd: HIP error %s at %s:%d (%s)\n",             \
-                    hipGetErrorString(e_), __FILE__, __LINE__, #call);              \
-            abort();                                                                \
-        }                                                                           \
-    } while (0)
-
-/* ------------------------------------------------------------------------ */
-/* element access helpers                                                    */
-/* ------------------------------------------------------------------------ */
-
-template <bool VEC>
-FA_DEV cplx load_elem(const double *p, i64 a, i64 im, int flags) {
-    cplx v;
-    if (VEC) {
-        v = *reinterpret_cast<const cplx *>(p + a);
-    } else {
-        v.x = p[a];
-        v.y = (flags & FFTW_AMD_F_REAL_IN) ? 0.0 : p[a + im];
-    }
-    if (flags & FFTW_AMD_F_SWAP_IN) { double t = v.x; v.x = v.y; v.y = t; }
-    return v;
-}
-
-template <bool VEC>
-FA_DEV void store_elem(double *p, i64 a, i64 im, int flags, cplx v) {
-    if (flags & FFTW_AMD_F_CONJ_OUT) v.y = -v.y;
-    if (flags & FFTW_AMD_F_SWAP_OUT) { double t = v.x; v.x = v.y; v.y = t; }
-    if (VEC) {
-        *reinterpret_cast<cplx *>(p + a) = v;
-    } else {
-        p[a] = v.x;
-        if (!(flags & FFTW_AMD_F_REAL_OUT)) p[a + im] = v.y;
-    }
-}
-
-/* w^m from the two-level table: (cos, sin)(2 pi m / n) */
-FA_DEV cplx tw2(const cplx *lo, const cplx *hi, int shift, i64 m) {
-    cplx a = lo[m & ((1LL << shift) - 1)];
-    cplx b = hi[m >> shift];
-    return c_mul(a, b);
-}
-
-static inline i64 iabs64(i64 v) { return v < 0 ? -v : v; }
+#include "common.hpp"
 
 #include "pass1024.hpp"
 #include "stream1024.hpp"
@@ -510,11 +453,6 @@ static void grid_for(i64 total, dim3 *grid) {
     *grid = dim3((unsigned)blocks, 1, 1);
 }
 
-/* offsets applied for the current batch chunk: user buffers advance, scratch
-   buffers are reused per chunk */
-static inline i64 chunk_adv(int buf, i64 chunk_start, i64 stride) {
-    return (buf < 2) ? chunk_start * stride : 0;
-}
 
 static int g_lds_attr_done = 0;
 
@@ -522,6 +460,10 @@ template <bool VIN, bool VOUT>
 static void launch_pass_variant(const PassArgs &pa, dim3 grid, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL((pass_generic_kernel<VIN, VOUT>), grid, dim3(256), lds, st, pa);
 }
+
+/* kernels_rr.hip */
+int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                     i64 cs, i64 cn, hipStream_t st);
 
 template <bool IN_T, bool OUT_T, int HAS_TW>
 static void launch_p1024_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
@@ -625,6 +567,7 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
                        i64 cs, i64 cn, hipStream_t st) {
     PassArgs pa;
     if (d->variant == FFTW_AMD_K_P1024 && launch_p1024(d, bufs, tables, cs, cn, st) == 0) return 0;
+    if (d->variant == FFTW_AMD_K_RR && fa_launch_passrr(d, bufs, tables, cs, cn, st) == 0) return 0;
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
     for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {

@@ -1,0 +1,94 @@
+/*
+ * kernels_rr.hip -- instantiations and launcher of the two-stage register
+ * kernels for L = 64, 128, 256, 512 (passrr.hpp).  A translation unit of its
+ * own so that it compiles in parallel with kernels.hip.
+ */
+#include "common.hpp"
+#include "pass1024.hpp"
+#include "passrr.hpp"
+
+template <int R1, int R2, bool IN_T, bool OUT_T, int TW>
+static void launch_rr_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    const size_t lds = RRGeom<R1, R2>::lds_doubles * sizeof(double);
+    if (!attr_done) {
+        FA_CHECK(hipFuncSetAttribute((const void *)passrr_kernel<R1, R2, IN_T, OUT_T, TW>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((passrr_kernel<R1, R2, IN_T, OUT_T, TW>), grid, dim3(256), lds, st, pa);
+}
+
+/* the lane mappings that occur in plans: column passes (T,T) with any twiddle
+   mode, the transposing last pass (L,T) without or with input twiddle, and the
+   contiguous single pass (L,L).  Anything else falls back to the generic kernel. */
+template <int R1, int R2>
+static int dispatch_rr(const P1024Args &pa, dim3 grid, hipStream_t st, bool in_t, bool out_t, int tw) {
+    if (in_t && out_t) {
+        if (tw == 0) { launch_rr_variant<R1, R2, true, true, 0>(pa, grid, st); return 0; }
+        if (tw == 1) { launch_rr_variant<R1, R2, true, true, 1>(pa, grid, st); return 0; }
+        launch_rr_variant<R1, R2, true, true, 2>(pa, grid, st);
+        return 0;
+    }
+    if (!in_t && out_t) {
+        if (tw == 0) { launch_rr_variant<R1, R2, false, true, 0>(pa, grid, st); return 0; }
+        if (tw == 2) { launch_rr_variant<R1, R2, false, true, 2>(pa, grid, st); return 0; }
+        return 1;
+    }
+    if (!in_t && !out_t && tw == 0) { launch_rr_variant<R1, R2, false, false, 0>(pa, grid, st); return 0; }
+    return 1;
+}
+
+int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                     i64 cs, i64 cn, hipStream_t st) {
+    P1024Args pa;
+    int bd = d->batch_dim, T;
+    i64 sbase = d->src_base, dbase = d->dst_base;
+    if (d->src_im != 1 || d->dst_im != 1 ||
+        (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
+        return 1;
+    if (d->L != 64 && d->L != 128 && d->L != 256 && d->L != 512) return 1;
+    T = 8192 / d->L;
+    for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+        pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+        pa.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+        pa.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+        pa.dtw[i] = (i < d->ndims) ? d->dim_tw[i] : 0;
+    }
+    if (bd >= 0) {
+        sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+        dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+        pa.dn[bd] = cn;
+    }
+    pa.src = bufs[d->src_buf] + sbase;
+    pa.dst = bufs[d->dst_buf] + dbase;
+    pa.is_l = d->is_l;
+    pa.os_l = d->os_l;
+    if (((uintptr_t)pa.src % 16) || ((uintptr_t)pa.dst % 16) || (pa.is_l % 2) || (pa.os_l % 2)) return 1;
+    for (int i = 0; i < d->ndims; ++i)
+        if ((pa.dis[i] % 2) || (pa.dos[i] % 2)) return 1;
+    pa.w1024 = (const cplx *)tables[d->table];
+    pa.tw_shift = d->tw_shift;
+    pa.tw_lo = d->tw_n ? (const cplx *)tables[d->tw_lo] : NULL;
+    pa.tw_hi = d->tw_n ? (const cplx *)tables[d->tw_hi] : NULL;
+    pa.ndims = d->ndims;
+    pa.flags = d->flags;
+    pa.ntiles = (pa.dn[0] + T - 1) / T;
+    i64 nblocks = pa.ntiles;
+    for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
+    if (nblocks <= 0) return 0;
+    if (nblocks > 0x7fffffffLL) return 1;
+    /* a tile that would be mostly empty is better served by the generic kernel */
+    if (pa.dn[0] * 4 < T) return 1;
+    dim3 grid((unsigned)nblocks, 1, 1);
+    bool in_t = pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l);
+    bool out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);
+    int tw = d->tw_n == 0 ? 0 : ((d->flags & FFTW_AMD_F_TW_IN) ? 2 : 1);
+    switch (d->L) {
+    case 64:  return dispatch_rr<8, 8>(pa, grid, st, in_t, out_t, tw);
+    case 128: return dispatch_rr<16, 8>(pa, grid, st, in_t, out_t, tw);
+    case 256: return dispatch_rr<16, 16>(pa, grid, st, in_t, out_t, tw);
+    case 512: return dispatch_rr<32, 16>(pa, grid, st, in_t, out_t, tw);
+    }
+    return 1;
+}

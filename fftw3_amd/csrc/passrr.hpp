@@ -1,0 +1,222 @@
+/*
+ * passrr.hpp -- register-resident two-stage pass for L = R1 * R2 in {64, 128, 256, 512}.
+ *
+ * Same design as pass1024.hpp (which is the R1 = R2 = 32 member of the family,
+ * kept separately because it is the measured hot kernel): a workgroup of 256
+ * work-items owns a tile of 8192 complex doubles = T sequences of length L
+ * (T = 8192 / L = 16 .. 128), every work-item keeps 32 elements in registers,
+ * the DFT-L is   radix-R1 butterflies  ->  w_L^(a d)  ->  one LDS exchange  ->
+ * radix-R2 butterflies, and the tile is T sequences wide so that global access
+ * is in segments of at least T * 16 B >= 256 B.
+ *
+ * With R < 32 a work-item owns Q = 32 / R butterflies per stage:
+ *   stage 1: butterfly g = u*256 + tid  (u < Q1)  over l = a + R2 i,   (a, t) from g
+ *   stage 2: butterfly h = v*256 + tid  (v < Q2)  over a,  output k = d + R1 c, (d, t) from h
+ * The lane -> (a, t) / (d, t) maps put t (column pass) or a / d (row pass)
+ * fastest across lanes, exactly like IN_T / OUT_T of pass1024.hpp.
+ *
+ * Reference counterpart: the same Cooley-Tukey node the reference executes as
+ * dftw_direct_apply over a t1_R codelet plus direct_apply over an n1_R codelet
+ * (fftw/fftw_api.c:2315-2324, 3182-3205; fftw/dft_scalar/codelets/t1_16.c,
+ * n1_16.c, t1_8.c, n1_8.c ...).
+ */
+#ifndef FA_PASSRR_HPP
+#define FA_PASSRR_HPP
+
+/* radix-R butterfly with its output permutation */
+template <int R> struct RB;
+template <> struct RB<8> {
+    static FA_DEV void run(cplx *x) { Bfly<8>::run(x); }
+    static constexpr int slot(int k) { return k; }
+    static constexpr int bits = 3;
+};
+template <> struct RB<16> {
+    static FA_DEV void run(cplx *x) { Bfly<16>::run(x); }
+    static constexpr int slot(int k) { return k; }
+    static constexpr int bits = 4;
+};
+template <> struct RB<32> {
+    static FA_DEV void run(cplx *x) { bfly32(x); }
+    static constexpr int slot(int k) { return slot32(k); }
+    static constexpr int bits = 5;
+};
+
+/* x[slot(D)] *= conj(prefix * w^D), D in [0, 2^bits): product tree over the bits of D */
+template <int R, int BIT, int D, bool HAVE, bool PERM> struct TwTreeR {
+    static FA_DEV void run(cplx *x, const cplx *pw, cplx acc) {
+        TwTreeR<R, BIT - 1, D, HAVE, PERM>::run(x, pw, acc);
+        cplx nxt = HAVE ? c_mul(acc, pw[BIT]) : pw[BIT];
+        TwTreeR<R, BIT - 1, D + (1 << BIT), true, PERM>::run(x, pw, nxt);
+    }
+};
+template <int R, int D, bool HAVE, bool PERM> struct TwTreeR<R, -1, D, HAVE, PERM> {
+    static FA_DEV void run(cplx *x, const cplx *, cplx acc) {
+        constexpr int S = PERM ? RB<R>::slot(D) : D;
+        if (HAVE) x[S] = c_mulc(x[S], acc);
+    }
+};
+
+template <int R1, int R2> struct RRGeom {
+    static constexpr int L = R1 * R2;
+    static constexpr int T = 8192 / L;
+    static constexpr int Q1 = 32 / R1;
+    static constexpr int Q2 = 32 / R2;
+    /* LDS image of one real plane: element (d, a, t), padded against bank conflicts */
+    template <bool IN_T, bool OUT_T> static FA_DEV int idx(int d, int a, int t) {
+        if (IN_T && OUT_T) return d * (R2 * T + (T < 32 ? T : 0)) + a * T + t;
+        if (!IN_T && OUT_T) return d * (T * (R2 + 1)) + t * (R2 + 1) + a;
+        if (IN_T && !OUT_T) return a * (T * (R1 + 1)) + t * (R1 + 1) + d;
+        return t * (R1 * (R2 + 1)) + d * (R2 + 1) + a;
+    }
+    static constexpr int lds_doubles = 8192 + (R1 > R2 ? R1 : R2) * T + 64;
+};
+
+struct PRRTile {
+    const double *src;
+    double *dst;
+    i64 is_l, os_l;
+    i64 dis0, dos0;
+    i64 dtw0, q0;
+    const cplx *wL;
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    int tw_shift;
+    int Tcur;
+    int flags;
+};
+
+template <int R1, int R2, bool IN_T, bool OUT_T, int HAS_TW>
+FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
+    typedef RRGeom<R1, R2> G;
+    constexpr int T = G::T, Q1 = G::Q1, Q2 = G::Q2;
+    cplx x[Q1][R1];
+    int a1[Q1], t1[Q1];
+
+    /* ---- load + stage 1 */
+#pragma unroll
+    for (int u = 0; u < Q1; ++u) {
+        const int g = u * 256 + tid;
+        t1[u] = IN_T ? (g % T) : (g / R2);
+        a1[u] = IN_T ? (g / T) : (g % R2);
+        const double *p = a.src + (i64)a1[u] * a.is_l + (i64)t1[u] * a.dis0;
+        const i64 step = (i64)R2 * a.is_l;
+        if (t1[u] < a.Tcur) {
+#pragma unroll
+            for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + i * step);
+        } else {
+#pragma unroll
+            for (int i = 0; i < R1; ++i) x[u][i] = c_make(0.0, 0.0);
+        }
+    }
+    if (a.flags & FFTW_AMD_F_SWAP_IN) {
+#pragma unroll
+        for (int u = 0; u < Q1; ++u)
+#pragma unroll
+            for (int i = 0; i < R1; ++i) { double s = x[u][i].x; x[u][i].x = x[u][i].y; x[u][i].y = s; }
+    }
+#pragma unroll
+    for (int u = 0; u < Q1; ++u) {
+        if (HAS_TW == 2) {
+            /* conj(w_N^((a + R2 i) q)) on the input */
+            const i64 q = a.q0 + (i64)t1[u] * a.dtw0;
+            cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * a1[u]);
+            cplx pw[RB<R1>::bits];
+#pragma unroll
+            for (int s = 0; s < RB<R1>::bits; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * R2) << s);
+            TwTreeR<R1, RB<R1>::bits - 1, 0, true, false>::run(x[u], pw, base);
+        }
+        RB<R1>::run(x[u]);
+        {
+            cplx pw[RB<R1>::bits];
+#pragma unroll
+            for (int s = 0; s < RB<R1>::bits; ++s) pw[s] = a.wL[a1[u] << s];
+            TwTreeR<R1, RB<R1>::bits - 1, 0, false, true>::run(x[u], pw, c_make(1.0, 0.0));
+        }
+    }
+
+    /* ---- exchange, one real plane at a time */
+    cplx y[Q2][R2];
+    int d2[Q2], t2[Q2];
+#pragma unroll
+    for (int v = 0; v < Q2; ++v) {
+        const int h = v * 256 + tid;
+        t2[v] = OUT_T ? (h % T) : (h / R1);
+        d2[v] = OUT_T ? (h / T) : (h % R1);
+    }
+#pragma unroll
+    for (int u = 0; u < Q1; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[G::template idx<IN_T, OUT_T>(d, a1[u], t1[u])] = x[u][RB<R1>::slot(d)].x;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < Q2; ++v)
+#pragma unroll
+        for (int q = 0; q < R2; ++q) y[v][q].x = plane[G::template idx<IN_T, OUT_T>(d2[v], q, t2[v])];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < Q1; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[G::template idx<IN_T, OUT_T>(d, a1[u], t1[u])] = x[u][RB<R1>::slot(d)].y;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < Q2; ++v)
+#pragma unroll
+        for (int q = 0; q < R2; ++q) y[v][q].y = plane[G::template idx<IN_T, OUT_T>(d2[v], q, t2[v])];
+
+    /* ---- stage 2, output twiddle, store: X[d + R1 c] */
+#pragma unroll
+    for (int v = 0; v < Q2; ++v) {
+        RB<R2>::run(y[v]);
+        if (HAS_TW == 1) {
+            const i64 q = a.q0 + (i64)t2[v] * a.dtw0;
+            cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * d2[v]);
+            cplx pw[RB<R2>::bits];
+#pragma unroll
+            for (int s = 0; s < RB<R2>::bits; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * R1) << s);
+            TwTreeR<R2, RB<R2>::bits - 1, 0, true, true>::run(y[v], pw, base);
+        }
+        if (t2[v] < a.Tcur) {
+            double *p = a.dst + (i64)d2[v] * a.os_l + (i64)t2[v] * a.dos0;
+            const i64 step = (i64)R1 * a.os_l;
+            const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
+#pragma unroll
+            for (int c = 0; c < R2; ++c) {
+                cplx w = y[v][RB<R2>::slot(c)];
+                if (sw) { double s = w.x; w.x = w.y; w.y = s; }
+                *reinterpret_cast<cplx *>(p + c * step) = w;
+            }
+        }
+    }
+}
+
+/* kernel arguments are those of pass1024 (P1024Args): same dims / strides / tables */
+template <int R1, int R2, bool IN_T, bool OUT_T, int HAS_TW>
+__global__ void __launch_bounds__(256, 2)
+passrr_kernel(const P1024Args a) {
+    extern __shared__ __attribute__((aligned(16))) double plane[];
+    constexpr int T = RRGeom<R1, R2>::T;
+    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
+    i64 tile = blk % a.ntiles;
+    i64 rest = blk / a.ntiles;
+    i64 soff = 0, doff = 0, twb = 0;
+    for (int d = 1; d < a.ndims; ++d) {
+        i64 idx = rest % a.dn[d];
+        rest /= a.dn[d];
+        soff += idx * a.dis[d];
+        doff += idx * a.dos[d];
+        twb += idx * a.dtw[d];
+    }
+    const i64 t0 = tile * T;
+    PRRTile t;
+    t.src = a.src + soff + t0 * a.dis[0];
+    t.dst = a.dst + doff + t0 * a.dos[0];
+    t.is_l = a.is_l; t.os_l = a.os_l;
+    t.dis0 = a.dis[0]; t.dos0 = a.dos[0];
+    t.dtw0 = a.dtw[0]; t.q0 = twb + t0 * a.dtw[0];
+    t.wL = a.w1024; t.tw_lo = a.tw_lo; t.tw_hi = a.tw_hi; t.tw_shift = a.tw_shift;
+    t.Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
+    t.flags = a.flags;
+    prr_tile<R1, R2, IN_T, OUT_T, HAS_TW>(t, plane, threadIdx.x);
+}
+
+#endif /* FA_PASSRR_HPP */

@@ -88,7 +88,8 @@ enum {
 
 enum {
     FFTW_AMD_K_GENERIC = 0,     /* runtime-radix LDS kernel */
-    FFTW_AMD_K_P1024 = 1        /* register-resident radix-32x32 kernel, tile of 8 */
+    FFTW_AMD_K_P1024 = 1,       /* register-resident radix-32x32 kernel, tile of 8 */
+    FFTW_AMD_K_RR = 2           /* register-resident two-stage kernel, L = 64..512, tile of 8192/L */
 };
 
 enum {
