@@ -23,12 +23,12 @@
 
 typedef struct fftw_plan_s plan;
 
-static size_t g_chunk_bytes = (size_t)256 << 20;
+static size_t g_chunk_bytes = (size_t)1 << 30;
 static i64 g_lmax_multi = 1024;
 static int g_pipeline = 1;
 static int g_fused = 0, g_fused_lag = 5, g_fused_slots = 10;   /* opt-in: FFTW_AMD_FUSED=1 */
 
-void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : ((size_t)256 << 20); }
+void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : ((size_t)1 << 30); }
 
 static i64 iabs(i64 v) { return v < 0 ? -v : v; }
 
@@ -1114,7 +1114,7 @@ int fa_device_init(plan *p) {
         !p->single_chunk && g_pipeline) {
         i64 per = 0;
         for (i = 2; i < p->nbufs; ++i) per += p->buf_reals[i];
-        if (per > 0 && (size_t)per * sizeof(double) * 3 <= ((size_t)1 << 31)) {
+        if (per > 0 && (size_t)per * sizeof(double) * 3 <= ((size_t)8 << 30)) {
             p->nslots = 3;
             p->split = p->nsteps / 2;
             p->pstream[0] = fa_hip_stream_create();

@@ -37,7 +37,7 @@ void fftw_amd_plan_sync(fftw_plan p);
 size_t fftw_amd_plan_workspace_bytes(const fftw_plan p);
 
 /* Upper bound, in bytes, for the scratch that one chunk of a multi-pass plan
-   may occupy (default 256 MiB; three such slots are pipelined).  Measured on
+   may occupy (default 1 GiB; three such slots are pipelined).  Measured on
    MI355X: smaller chunks keep the intermediate in the Infinity Cache but gain
    nothing, because cache hits and HBM misses share the ~7 TB/s fabric
    (profiles/r01_membw.txt), while they pay more launches.  0 restores the
