@@ -69,6 +69,24 @@ def workload(name, batch_override):
     return n, b, kind, flops, abytes
 
 
+def pmc_traffic(step, units):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
+    FETCH_SIZE doubled as the MI355X guide prescribes).  Counters cannot be read inside
+    this process; the per-transform figure measured on the same kernel is scaled to the
+    transforms one launch processes.  None when the kernel has no committed measurement."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if step.L != 1024 or step.variant != 1 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        prof = json.load(f)
+    key = "pass1024_kernel<false, true, 2>" if step.tw_n else "pass1024_kernel<true, true, 0>"
+    for name, v in prof["kernels"].items():
+        if key in name:
+            return v["traffic_bytes_per_transform"] * units
+    return None
+
+
 def cpu_baseline(n, kind, flops_per_transform, target_seconds=12.0):
     """the oracle (a port, one core) on a bounded sample of the same workload"""
     import numpy as np
@@ -195,7 +213,7 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(st, units),
             "kernel": "step%d kind=%d L=%d variant=%d" % (prof.index(dom), st.kind, st.L, st.variant),
             "avg_launch_ms": avg_ms, "launches_per_step": launches,
             "alg_bytes_per_launch": bytes_per_launch,
