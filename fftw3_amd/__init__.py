@@ -43,6 +43,7 @@ MAX_DIMS = 8
 MAX_RADICES = 16
 
 STEP_PASS, STEP_COPY, STEP_R2C_POST, STEP_C2R_PRE, STEP_RADER_MUL, STEP_HERM_EXPAND = 1, 2, 3, 4, 5, 6
+STEP_R2C_POST4, STEP_C2R_PRE4 = 7, 8
 F_SWAP_IN, F_SWAP_OUT, F_REAL_IN, F_REAL_OUT = 1, 2, 4, 8
 F_MUL_TABLE, F_MUL_CONJ, F_PERM_SRC, F_PERM_DST, F_CONJ_OUT, F_TW_IN = 16, 32, 64, 128, 256, 512
 
@@ -66,6 +67,7 @@ class StepDesc(C.Structure):
         ("table", C.c_int), ("table2", C.c_int),
         ("aux_buf", C.c_int), ("aux_base", C.c_longlong),
         ("variant", C.c_int),
+        ("tile_lo_n", C.c_int), ("tile_lo_is", C.c_longlong), ("tile_lo_os", C.c_longlong),
     ]
 
 

@@ -66,6 +66,7 @@ typedef struct {
     fa_dim loops[FA_MAXLOOPS];
     int batch_loop;             /* index of the chunked loop or -1 */
     int flags_in, flags_out;    /* FFTW_AMD_F_* that apply at the first / last step */
+    int dense;                  /* the axis interleaved with a 2-element loop is contiguous memory */
 } fa_axis;
 
 struct fftw_plan_s {

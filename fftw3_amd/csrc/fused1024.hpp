@@ -151,6 +151,7 @@ fused1024_kernel(const Fused1024Args a) {
         P1024Tile t;
         t.w1024 = a.w1024; t.tw_lo = a.tw_lo; t.tw_hi = a.tw_hi; t.tw_shift = a.tw_shift;
         t.Tcur = 8;
+        t.lo_sh = 0; t.lo_is = 0; t.lo_os = 0;
         double *slot = a.scratch + (b % a.nslots) * (2 * N1 * N1);
         if (kind == 0) {
             /* pass 1: columns 8*tile .. +7 of the [1024][1024] view, stride 1024 between rows.

@@ -40,6 +40,8 @@ struct PassArgs {
     int rad[FFTW_AMD_MAX_RADICES];
     int ndims, T, ld, flags;
     int in_t_fast, out_t_fast;
+    int lo_n;              /* inner tile component (1: none); T counts lo_n * hi entries */
+    i64 lo_is, lo_os;
 };
 
 template <int R>
@@ -112,8 +114,9 @@ pass_generic_kernel(const PassArgs a) {
         doff += idx * a.dos[d];
         twb += idx * a.dtw[d];
     }
-    const i64 t0 = tile * a.T;
-    const int Tcur = (int)((a.dn[0] - t0 < a.T) ? (a.dn[0] - t0) : a.T);
+    const int Thi = a.T / a.lo_n;
+    const i64 t0 = tile * Thi;
+    const int Tcur = (int)((a.dn[0] - t0 < Thi) ? (a.dn[0] - t0) : Thi) * a.lo_n;
     const int L = a.L, ld = a.ld;
     const int total = L * Tcur;
     const bool tw_in = a.tw_n && (a.flags & FFTW_AMD_F_TW_IN);
@@ -123,10 +126,11 @@ pass_generic_kernel(const PassArgs a) {
         int l, t;
         if (a.in_t_fast) { l = e / Tcur; t = e - l * Tcur; }
         else             { t = e / L;    l = e - t * L; }
-        i64 addr = soff + (i64)l * a.is_l + (t0 + t) * a.dis[0];
+        const int thi = t / a.lo_n, tlo = t - thi * a.lo_n;
+        i64 addr = soff + (i64)l * a.is_l + (t0 + thi) * a.dis[0] + tlo * a.lo_is;
         cplx v = load_elem<VIN>(a.src, addr, a.src_im, a.flags);
         if (tw_in) {
-            i64 m = (i64)l * (twb + (t0 + t) * a.dtw[0]);
+            i64 m = (i64)l * (twb + (t0 + thi) * a.dtw[0]);
             v = c_mulc(v, tw2(a.tw_lo, a.tw_hi, a.tw_shift, m));
         }
         A[l * ld + t] = v;
@@ -160,11 +164,12 @@ pass_generic_kernel(const PassArgs a) {
         if (a.out_t_fast) { l = e / Tcur; t = e - l * Tcur; }
         else              { t = e / L;    l = e - t * L; }
         cplx v = A[l * ld + t];
+        const int thi = t / a.lo_n, tlo = t - thi * a.lo_n;
         if (a.tw_n && !tw_in) {
-            i64 m = (i64)l * (twb + (t0 + t) * a.dtw[0]);
+            i64 m = (i64)l * (twb + (t0 + thi) * a.dtw[0]);
             v = c_mulc(v, tw2(a.tw_lo, a.tw_hi, a.tw_shift, m));
         }
-        i64 addr = doff + (i64)l * a.os_l + (t0 + t) * a.dos[0];
+        i64 addr = doff + (i64)l * a.os_l + (t0 + thi) * a.dos[0] + tlo * a.lo_os;
         store_elem<VOUT>(a.dst, addr, a.dst_im, a.flags, v);
     }
 }
@@ -293,6 +298,127 @@ __global__ void __launch_bounds__(256) c2r_pre_kernel(const RealArgs a) {
         store_elem<false>(a.dst, doff + k * a.os_k, a.dst_im, a.flags, zk);
         if (km != k && km != a.h)
             store_elem<false>(a.dst, doff + km * a.os_k, a.dst_im, a.flags, zm);
+    }
+}
+
+
+/* ------------------------------------------------------------------------ */
+/* radix-4 r2c untangle / c2r tangle                                         */
+/* ------------------------------------------------------------------------ */
+/* n = 4m.  z_v[j] = x[4j+2v] + i x[4j+2v+1] (v = 0,1), Z_v = DFT_m(z_v) stored
+   as [v][m].  With X_s = DFT_m(x[4j+s]):  X_{2v} = (Z_v[k] + conj Z_v[m-k]) / 2,
+   X_{2v+1} = -i (Z_v[k] - conj Z_v[m-k]) / 2, T_s = w_n^(sk) X_s, and
+       Y[k]    = T0 + T1 + T2 + T3        Y[k+m]  = T0 - iT1 - T2 + iT3
+       Y[2m-k] = conj(T0 - T1 + T2 - T3)  Y[m-k]  = conj(T0 + iT1 - T2 - iT3)
+   This is the reference's rdft2-ct-dit/4 step with the hc2cfdft_4 codelet
+   (fftw/fftw_api.c:5579-5590, fftw/rdft_scalar/r2cf/hc2cfdft_4.c:135-212), the
+   plan it picks for n = 2^22. */
+struct Real4Args {
+    const double *src;   /* Z: element k of vector v at src + v*vs + k*is_k */
+    double *dst;
+    i64 src_im, dst_im;
+    i64 is_k, vs, os_k;
+    i64 m, npair, total;
+    i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    int tw_shift;
+    int ndims, flags;
+};
+
+__global__ void __launch_bounds__(256) r2c_post4_kernel(const Real4Args a) {
+    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; gid < a.total; gid += stride) {
+        i64 k = gid % a.npair;
+        i64 rest = gid / a.npair;
+        i64 soff = 0, doff = 0;
+        for (int d = 0; d < a.ndims; ++d) {
+            i64 idx = rest % a.dn[d];
+            rest /= a.dn[d];
+            soff += idx * a.dis[d];
+            doff += idx * a.dos[d];
+        }
+        const i64 m = a.m, km = (k == 0) ? 0 : m - k;
+        cplx T[4];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            cplx zk = load_elem<false>(a.src, soff + v * a.vs + k * a.is_k, a.src_im, 0);
+            cplx zm = load_elem<false>(a.src, soff + v * a.vs + km * a.is_k, a.src_im, 0);
+            cplx E = c_make(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+            cplx D = c_make(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
+            T[2 * v] = E;
+            T[2 * v + 1] = c_mni(D);
+        }
+        T[1] = c_mulc(T[1], tw2(a.tw_lo, a.tw_hi, a.tw_shift, k));
+        T[2] = c_mulc(T[2], tw2(a.tw_lo, a.tw_hi, a.tw_shift, 2 * k));
+        T[3] = c_mulc(T[3], tw2(a.tw_lo, a.tw_hi, a.tw_shift, 3 * k));
+        cplx s02 = c_add(T[0], T[2]), d02 = c_sub(T[0], T[2]);
+        cplx s13 = c_add(T[1], T[3]), d13 = c_sub(T[1], T[3]);
+        cplx y0 = c_add(s02, s13);                 /* Y[k]       */
+        cplx y1 = c_add(d02, c_mni(d13));          /* Y[k+m]     */
+        cplx y2 = c_sub(s02, s13);  y2.y = -y2.y;  /* Y[2m-k]    */
+        cplx y3 = c_add(d02, c_mpi(d13)); y3.y = -y3.y;   /* Y[m-k] */
+        if (k == 0) { y0.y = 0.0; y2.y = 0.0; }
+        store_elem<false>(a.dst, doff + k * a.os_k, a.dst_im, a.flags, y0);
+        store_elem<false>(a.dst, doff + (k + m) * a.os_k, a.dst_im, a.flags, y1);
+        store_elem<false>(a.dst, doff + (2 * m - k) * a.os_k, a.dst_im, a.flags, y2);
+        if (k != 0 && 2 * k != m) store_elem<false>(a.dst, doff + (m - k) * a.os_k, a.dst_im, a.flags, y3);
+    }
+}
+
+/* c2r: with A = Y[k], B = Y[k+m], C = conj Y[2m-k], D = conj Y[m-k]:
+       S0 = A+B+C+D, S1 = A+iB-C-iD, S2 = A-B+C-D, S3 = A-iB-C+iD,
+       X'_s = w_n^(-sk) S_s,  Z'_0[k] = X'_0 + i X'_1,  Z'_1[k] = X'_2 + i X'_3;
+   the mirror index m-k uses the same four loads with conjugated roles. */
+FA_DEV void c2r4_combine(cplx A, cplx B, cplx C, cplx D, cplx w1, cplx w2, cplx w3, cplx *z0, cplx *z1) {
+    cplx sAC = c_add(A, C), dAC = c_sub(A, C), sBD = c_add(B, D), dBD = c_sub(B, D);
+    cplx S0 = c_add(sAC, sBD);
+    cplx S1 = c_add(dAC, c_mpi(dBD));
+    cplx S2 = c_sub(sAC, sBD);
+    cplx S3 = c_add(dAC, c_mni(dBD));
+    cplx X1 = c_mul(S1, w1), X2 = c_mul(S2, w2), X3 = c_mul(S3, w3);
+    *z0 = c_add(S0, c_mpi(X1));
+    *z1 = c_add(X2, c_mpi(X3));
+}
+
+__global__ void __launch_bounds__(256) c2r_pre4_kernel(const Real4Args a) {
+    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; gid < a.total; gid += stride) {
+        i64 k = gid % a.npair;
+        i64 rest = gid / a.npair;
+        i64 soff = 0, doff = 0;
+        for (int d = 0; d < a.ndims; ++d) {
+            i64 idx = rest % a.dn[d];
+            rest /= a.dn[d];
+            soff += idx * a.dis[d];
+            doff += idx * a.dos[d];
+        }
+        const i64 m = a.m;
+        /* the four half-spectrum entries this pair needs (src here is Y, is_k its stride) */
+        cplx Yk = load_elem<false>(a.src, soff + k * a.is_k, a.src_im, 0);
+        cplx Ykm = load_elem<false>(a.src, soff + (k + m) * a.is_k, a.src_im, 0);
+        cplx Y2 = load_elem<false>(a.src, soff + (2 * m - k) * a.is_k, a.src_im, 0);
+        cplx Y1 = load_elem<false>(a.src, soff + (m - k) * a.is_k, a.src_im, 0);
+        if (k == 0) { Yk.y = 0.0; Y2.y = 0.0; }      /* Im Y[0], Im Y[n/2] are ignored */
+        cplx w1 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k);
+        cplx w2 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 2 * k);
+        cplx w3 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 3 * k);
+        cplx z0, z1;
+        c2r4_combine(Yk, Ykm, c_make(Y2.x, -Y2.y), c_make(Y1.x, -Y1.y), w1, w2, w3, &z0, &z1);
+        store_elem<false>(a.dst, doff + k * a.os_k, a.dst_im, a.flags, z0);
+        store_elem<false>(a.dst, doff + a.vs + k * a.os_k, a.dst_im, a.flags, z1);
+        if (k != 0 && 2 * k != m) {
+            /* mirror k' = m-k: A' = Y[m-k], B' = Y[2m-k], C' = conj Y[m+k], D' = conj Y[k];
+               w_n^(-s(m-k)) = i^s conj(w_s) */
+            cplx v1 = c_mpi(c_make(w1.x, -w1.y));
+            cplx v2 = c_make(-w2.x, w2.y);
+            cplx v3 = c_mni(c_make(w3.x, -w3.y));
+            c2r4_combine(Y1, Y2, c_make(Ykm.x, -Ykm.y), c_make(Yk.x, -Yk.y), v1, v2, v3, &z0, &z1);
+            store_elem<false>(a.dst, doff + (m - k) * a.os_k, a.dst_im, a.flags, z0);
+            store_elem<false>(a.dst, doff + a.vs + (m - k) * a.os_k, a.dst_im, a.flags, z1);
+        }
     }
 }
 
@@ -511,7 +637,13 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
     pa.tw_hi = d->tw_n ? (const cplx *)tables[d->tw_hi] : NULL;
     pa.ndims = d->ndims;
     pa.flags = d->flags;
-    pa.ntiles = (pa.dn[0] + 7) / 8;
+    pa.lo_sh = 0; pa.lo_is = d->tile_lo_is; pa.lo_os = d->tile_lo_os;
+    if (d->tile_lo_n > 1) {
+        if (d->tile_lo_n != 2 && d->tile_lo_n != 4) return 1;
+        pa.lo_sh = d->tile_lo_n == 2 ? 1 : 2;
+        if ((pa.lo_is % 2) || (pa.lo_os % 2)) return 1;
+    }
+    pa.ntiles = (pa.dn[0] + (8 >> pa.lo_sh) - 1) / (8 >> pa.lo_sh);
     i64 nblocks = pa.ntiles;
     for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
     if (nblocks <= 0) return 0;
@@ -532,7 +664,7 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
             FA_CHECK(hipGetDeviceProperties(&prop, dev));
             ncu = prop.multiProcessorCount;
         }
-        if (stream_mode && nblocks >= 4 * (i64)ncu) {
+        if (stream_mode && nblocks >= 4 * (i64)ncu && pa.lo_sh == 0) {
             S1024Args sa;
             for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
                 sa.ps.dn[i] = pa.dn[i]; sa.ps.dis[i] = pa.dis[i]; sa.ps.dos[i] = pa.dos[i]; sa.ps.dtw[i] = pa.dtw[i];
@@ -597,10 +729,14 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
     for (int i = 0; i < FFTW_AMD_MAX_RADICES; ++i) pa.rad[i] = (i < d->nradices) ? d->radices[i] : 1;
     pa.ndims = d->ndims;
     pa.T = d->tile;
-    while (pa.T > 1 && (i64)d->L * (pa.T | 1) > 5120) --pa.T;   /* tile of a tuned variant may not fit here */
+    pa.lo_n = d->tile_lo_n > 1 ? d->tile_lo_n : 1;
+    pa.lo_is = d->tile_lo_is; pa.lo_os = d->tile_lo_os;
+    while (pa.T > pa.lo_n && (i64)d->L * (pa.T | 1) > 5120) pa.T -= pa.lo_n;   /* tile of a tuned variant may not fit here */
+    if (pa.T < pa.lo_n) pa.T = pa.lo_n;
+    pa.T -= pa.T % pa.lo_n;
     pa.ld = (pa.T > 1) ? (pa.T | 1) : 1;
     pa.flags = d->flags;
-    pa.ntiles = (pa.dn[0] + pa.T - 1) / pa.T;
+    pa.ntiles = (pa.dn[0] + pa.T / pa.lo_n - 1) / (pa.T / pa.lo_n);
     /* a stride-0 dim cannot be the coalescing index */
     pa.in_t_fast = (pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l)) || pa.L == 1;
     pa.out_t_fast = (pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l)) || pa.L == 1;
@@ -641,6 +777,8 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
         if (pa.dis[i] % 2) vin = false;
         if (pa.dos[i] % 2) vout = false;
     }
+    if (pa.lo_is % 2) vin = false;
+    if (pa.lo_os % 2) vout = false;
     if (vin && vout) launch_pass_variant<true, true>(pa, grid, lds, st);
     else if (vin) launch_pass_variant<true, false>(pa, grid, lds, st);
     else if (vout) launch_pass_variant<false, true>(pa, grid, lds, st);
@@ -737,6 +875,47 @@ extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bu
             hipLaunchKernelGGL(r2c_post_kernel, grid, dim3(256), 0, st, ra);
         else
             hipLaunchKernelGGL(c2r_pre_kernel, grid, dim3(256), 0, st, ra);
+        return 0;
+    }
+    case FFTW_AMD_STEP_R2C_POST4:
+    case FFTW_AMD_STEP_C2R_PRE4: {
+        Real4Args ra;
+        int bd = d->batch_dim;
+        i64 sbase = d->src_base, dbase = d->dst_base;
+        for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+            ra.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+            ra.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+            ra.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+        }
+        if (bd >= 0) {
+            sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+            dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+            ra.dn[bd] = cn;
+        }
+        ra.src = bufs[d->src_buf] + sbase;
+        ra.dst = bufs[d->dst_buf] + dbase;
+        ra.src_im = d->src_im;
+        ra.dst_im = d->dst_im;
+        ra.is_k = d->is_l;
+        ra.os_k = d->os_l;
+        ra.vs = d->aux_valid;            /* distance between the two quarter-length vectors */
+        ra.m = d->aux_n / 4;
+        ra.npair = (d->kind == FFTW_AMD_STEP_R2C_POST4) ? ra.m / 2 + 1 : ra.m / 2 + 1;
+        ra.tw_lo = (const cplx *)tables[d->tw_lo];
+        ra.tw_hi = (const cplx *)tables[d->tw_hi];
+        ra.tw_shift = d->tw_shift;
+        ra.ndims = d->ndims;
+        ra.flags = d->flags;
+        i64 total = ra.npair;
+        for (int i = 0; i < d->ndims; ++i) total *= ra.dn[i];
+        ra.total = total;
+        if (total <= 0) return 0;
+        dim3 grid;
+        grid_for(total, &grid);
+        if (d->kind == FFTW_AMD_STEP_R2C_POST4)
+            hipLaunchKernelGGL(r2c_post4_kernel, grid, dim3(256), 0, st, ra);
+        else
+            hipLaunchKernelGGL(c2r_pre4_kernel, grid, dim3(256), 0, st, ra);
         return 0;
     }
     case FFTW_AMD_STEP_RADER_MUL: {

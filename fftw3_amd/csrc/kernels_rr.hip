@@ -73,6 +73,13 @@ int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *con
     pa.tw_hi = d->tw_n ? (const cplx *)tables[d->tw_hi] : NULL;
     pa.ndims = d->ndims;
     pa.flags = d->flags;
+    pa.lo_sh = 0; pa.lo_is = d->tile_lo_is; pa.lo_os = d->tile_lo_os;
+    if (d->tile_lo_n > 1) {
+        if (d->tile_lo_n != 2 && d->tile_lo_n != 4) return 1;
+        pa.lo_sh = d->tile_lo_n == 2 ? 1 : 2;
+        if ((pa.lo_is % 2) || (pa.lo_os % 2)) return 1;
+    }
+    T >>= pa.lo_sh;                      /* hi entries per tile */
     pa.ntiles = (pa.dn[0] + T - 1) / T;
     i64 nblocks = pa.ntiles;
     for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];

@@ -137,9 +137,16 @@ struct P1024Tile {
     const cplx *tw_lo;
     const cplx *tw_hi;
     int tw_shift;
-    int Tcur;             /* sequences present in this tile (<= 8) */
+    int Tcur;             /* hi entries present in this tile */
     int flags;
+    /* two-level tile dim: sequence t = (t & lo_mask) + (t >> lo_sh) << lo_sh */
+    int lo_sh;
+    i64 lo_is, lo_os;
 };
+
+/* offset of sequence t of a tile on the source / destination side */
+#define FA_TILE_SOFF(a, t) ((i64)((t) >> (a).lo_sh) * (a).dis0 + (i64)((t) & ((1 << (a).lo_sh) - 1)) * (a).lo_is)
+#define FA_TILE_DOFF(a, t) ((i64)((t) >> (a).lo_sh) * (a).dos0 + (i64)((t) & ((1 << (a).lo_sh) - 1)) * (a).lo_os)
 
 /* HAS_TW: 0 none, 1 inter-pass twiddle on the output, 2 on the input.
    `plane` is FA_P1024_LDS_DOUBLES doubles of LDS.  All 256 work-items call. */
@@ -161,9 +168,9 @@ FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid, Hook &h
     const int ai = IN_T ? (tid >> 3) : (tid & 31);
     cplx x[32];
     {
-        const double *p = a.src + (i64)ai * a.is_l + (i64)ti * a.dis0;
+        const double *p = a.src + (i64)ai * a.is_l + FA_TILE_SOFF(a, ti);
         const i64 step = 32 * a.is_l;
-        if (ti < a.Tcur) {
+        if ((ti >> a.lo_sh) < a.Tcur) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) x[i] = *reinterpret_cast<const cplx *>(p + i * step);
         } else {
@@ -179,7 +186,7 @@ FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid, Hook &h
 
     /* ---- inter-pass twiddle on the input: conj(w_N^((ai + 32 i) q)) */
     if (HAS_TW == 2) {
-        const i64 q = a.q0 + (i64)ti * a.dtw0;
+        const i64 q = a.q0 + (i64)(ti >> a.lo_sh) * a.dtw0;
         cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * ai);
         cplx pw[5];
 #pragma unroll
@@ -219,7 +226,7 @@ FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid, Hook &h
 
     /* ---- inter-pass twiddle conj(w_N^((dq + 32 c) q)), q = position of this sequence */
     if (HAS_TW == 1) {
-        const i64 q = a.q0 + (i64)to * a.dtw0;
+        const i64 q = a.q0 + (i64)(to >> a.lo_sh) * a.dtw0;
         cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * dq);
         cplx pw[5];
 #pragma unroll
@@ -231,9 +238,9 @@ FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid, Hook &h
     if (ST_SC1) {
         /* wave-uniform descriptor over the tile's destination; per-lane byte offsets */
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, 0x7fffffff, 0x00020000);
-        const int off0 = (int)(((i64)dq * a.os_l + (i64)to * a.dos0) * 8);
+        const int off0 = (int)(((i64)dq * a.os_l + FA_TILE_DOFF(a, to)) * 8);
         const int step = (int)(32 * a.os_l * 8);
-        if (to < a.Tcur) {
+        if ((to >> a.lo_sh) < a.Tcur) {
 #pragma unroll
             for (int c = 0; c < 32; ++c) {
                 cplx v = y[slot32(c)];
@@ -242,8 +249,8 @@ FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid, Hook &h
                 __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, off0 + c * step, 0, 16);
             }
         }
-    } else if (to < a.Tcur) {
-        double *p = a.dst + (i64)dq * a.os_l + (i64)to * a.dos0;
+    } else if ((to >> a.lo_sh) < a.Tcur) {
+        double *p = a.dst + (i64)dq * a.os_l + FA_TILE_DOFF(a, to);
         const i64 step = 32 * a.os_l;
         const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
 #pragma unroll
@@ -272,6 +279,8 @@ struct P1024Args {
     i64 ntiles;
     int tw_shift;
     int ndims, flags;
+    int lo_sh;
+    i64 lo_is, lo_os;
 };
 
 template <bool IN_T, bool OUT_T, int HAS_TW>
@@ -289,15 +298,16 @@ pass1024_kernel(const P1024Args a) {
         doff += idx * a.dos[d];
         twb += idx * a.dtw[d];
     }
-    const i64 t0 = tile * 8;
+    const i64 t0 = tile * (8 >> a.lo_sh);
     P1024Tile t;
+    t.lo_sh = a.lo_sh; t.lo_is = a.lo_is; t.lo_os = a.lo_os;
     t.src = a.src + soff + t0 * a.dis[0];
     t.dst = a.dst + doff + t0 * a.dos[0];
     t.is_l = a.is_l; t.os_l = a.os_l;
     t.dis0 = a.dis[0]; t.dos0 = a.dos[0];
     t.dtw0 = a.dtw[0]; t.q0 = twb + t0 * a.dtw[0];
     t.w1024 = a.w1024; t.tw_lo = a.tw_lo; t.tw_hi = a.tw_hi; t.tw_shift = a.tw_shift;
-    t.Tcur = (int)((a.dn[0] - t0 < 8) ? (a.dn[0] - t0) : 8);
+    t.Tcur = (int)((a.dn[0] - t0 < (8 >> a.lo_sh)) ? (a.dn[0] - t0) : (8 >> a.lo_sh));
     t.flags = a.flags;
     p1024_tile<IN_T, OUT_T, HAS_TW>(t, plane, threadIdx.x);
 }

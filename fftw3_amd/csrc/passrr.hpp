@@ -83,6 +83,8 @@ struct PRRTile {
     int tw_shift;
     int Tcur;
     int flags;
+    int lo_sh;
+    i64 lo_is, lo_os;
 };
 
 template <int R1, int R2, bool IN_T, bool OUT_T, int HAS_TW>
@@ -98,9 +100,9 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
         const int g = u * 256 + tid;
         t1[u] = IN_T ? (g % T) : (g / R2);
         a1[u] = IN_T ? (g / T) : (g % R2);
-        const double *p = a.src + (i64)a1[u] * a.is_l + (i64)t1[u] * a.dis0;
+        const double *p = a.src + (i64)a1[u] * a.is_l + FA_TILE_SOFF(a, t1[u]);
         const i64 step = (i64)R2 * a.is_l;
-        if (t1[u] < a.Tcur) {
+        if ((t1[u] >> a.lo_sh) < a.Tcur) {
 #pragma unroll
             for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + i * step);
         } else {
@@ -118,7 +120,7 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
     for (int u = 0; u < Q1; ++u) {
         if (HAS_TW == 2) {
             /* conj(w_N^((a + R2 i) q)) on the input */
-            const i64 q = a.q0 + (i64)t1[u] * a.dtw0;
+            const i64 q = a.q0 + (i64)(t1[u] >> a.lo_sh) * a.dtw0;
             cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * a1[u]);
             cplx pw[RB<R1>::bits];
 #pragma unroll
@@ -168,15 +170,15 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
     for (int v = 0; v < Q2; ++v) {
         RB<R2>::run(y[v]);
         if (HAS_TW == 1) {
-            const i64 q = a.q0 + (i64)t2[v] * a.dtw0;
+            const i64 q = a.q0 + (i64)(t2[v] >> a.lo_sh) * a.dtw0;
             cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * d2[v]);
             cplx pw[RB<R2>::bits];
 #pragma unroll
             for (int s = 0; s < RB<R2>::bits; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * R1) << s);
             TwTreeR<R2, RB<R2>::bits - 1, 0, true, true>::run(y[v], pw, base);
         }
-        if (t2[v] < a.Tcur) {
-            double *p = a.dst + (i64)d2[v] * a.os_l + (i64)t2[v] * a.dos0;
+        if ((t2[v] >> a.lo_sh) < a.Tcur) {
+            double *p = a.dst + (i64)d2[v] * a.os_l + FA_TILE_DOFF(a, t2[v]);
             const i64 step = (i64)R1 * a.os_l;
             const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
 #pragma unroll
@@ -206,15 +208,16 @@ passrr_kernel(const P1024Args a) {
         doff += idx * a.dos[d];
         twb += idx * a.dtw[d];
     }
-    const i64 t0 = tile * T;
+    const i64 t0 = tile * (T >> a.lo_sh);
     PRRTile t;
+    t.lo_sh = a.lo_sh; t.lo_is = a.lo_is; t.lo_os = a.lo_os;
     t.src = a.src + soff + t0 * a.dis[0];
     t.dst = a.dst + doff + t0 * a.dos[0];
     t.is_l = a.is_l; t.os_l = a.os_l;
     t.dis0 = a.dis[0]; t.dos0 = a.dos[0];
     t.dtw0 = a.dtw[0]; t.q0 = twb + t0 * a.dtw[0];
     t.wL = a.w1024; t.tw_lo = a.tw_lo; t.tw_hi = a.tw_hi; t.tw_shift = a.tw_shift;
-    t.Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
+    t.Tcur = (int)((a.dn[0] - t0 < (T >> a.lo_sh)) ? (a.dn[0] - t0) : (T >> a.lo_sh));
     t.flags = a.flags;
     prr_tile<R1, R2, IN_T, OUT_T, HAS_TW>(t, plane, threadIdx.x);
 }

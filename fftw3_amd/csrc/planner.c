@@ -272,6 +272,7 @@ static fftw_amd_step_desc *new_step(plan *p, int kind) {
     s->batch_dim = -1;
     s->aux_buf = -1;
     s->tile = 1;
+    s->tile_lo_n = 1;
     s->variant = FFTW_AMD_K_GENERIC;
     return s;
 }
@@ -305,13 +306,19 @@ static int step_set_dims(plan *p, fftw_amd_step_desc *s, const sdim *d, int nd, 
 static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l,
                       const sdim *dims, int nd, i64 tw_n, int flags) {
     fftw_amd_step_desc *s = new_step(p, FFTW_AMD_STEP_PASS);
-    int i, best = -1;
+    int i, best = -1, pair = -1;
     i64 best_cost = 0, T;
     const i64 INF = (i64)1 << 60;
-    sdim dummy;
+    sdim dummy, dims_local[FFTW_AMD_MAX_DIMS + FA_MAXLOOPS];
+    /* the pair loop of interleaved vectors is reserved for the inner tile component */
+    for (i = 0; i < nd; ++i)
+        if (dims[i].n == 2 && !dims[i].is_batch && dims[i].tw == 0 &&
+            (iabs(dims[i].is) == 2 || iabs(dims[i].os) == 2) &&
+            (dims[i].is % 2) == 0 && (dims[i].os % 2) == 0) { pair = i; break; }
+    if (L * 3 > FA_LDS_ELEMS || FA_TILE_ELEMS / L < 2) pair = -1;   /* a tile must hold both members */
     for (i = 0; i < nd; ++i) {
         i64 ci, co, cost;
-        if (dims[i].n <= 1) continue;
+        if (dims[i].n <= 1 || i == pair) continue;
         ci = dims[i].is ? iabs(dims[i].is) : INF;
         co = dims[i].os ? iabs(dims[i].os) : INF;
         if (L > 1 && iabs(is_l) < ci) ci = iabs(is_l);
@@ -321,6 +328,28 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
             (cost == best_cost && dims[i].n > dims[best].n)) {
             best = i;
             best_cost = cost;
+        }
+    }
+    /* a two-element loop whose stride is one complex on either side (the two
+       interleaved vectors of a radix-4 real transform) becomes the inner
+       component of the tile dim: its pairs then share 32-byte accesses */
+    if (best < 0 && pair >= 0) { best = pair; pair = -1; }   /* nothing else to tile over */
+    {
+        sdim rest[FFTW_AMD_MAX_DIMS + FA_MAXLOOPS];
+        int lo = pair, k2 = 0;
+        if (lo >= 0) {
+            int nb = best;
+            s->tile_lo_n = 2;
+            s->tile_lo_is = dims[lo].is;
+            s->tile_lo_os = dims[lo].os;
+            for (i = 0; i < nd; ++i) {
+                if (i == lo) { if (i < best) --nb; continue; }
+                rest[k2++] = dims[i];
+            }
+            memcpy((void *)dims_local, rest, sizeof(sdim) * (size_t)k2);
+            dims = dims_local;
+            nd = k2;
+            best = nb;
         }
     }
     s->src_buf = src.buf; s->src_base = src.base; s->src_im = src.im;
@@ -346,9 +375,10 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
     }
     T = FA_TILE_ELEMS / L;
     if (T < 1) T = 1;
-    if (T > s->dim_n[0]) T = s->dim_n[0];
+    if (T > s->dim_n[0] * s->tile_lo_n) T = s->dim_n[0] * s->tile_lo_n;
     /* the LDS row is padded to an odd width (T | 1): both images must fit 160 KiB */
     while (T > 1 && L * (T | 1) > FA_LDS_ELEMS) --T;
+    T -= T % s->tile_lo_n;
     if (T < 1) T = 1;
     s->tile = (int)T;
     if (src.im == 1 && dst.im == 1 && !(flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT)) &&
@@ -356,7 +386,8 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
         if (L == 1024) {
             s->variant = FFTW_AMD_K_P1024;  /* register-resident radix-32x32, 8 sequences per tile */
             s->tile = 8;
-        } else if ((L == 64 || L == 128 || L == 256 || L == 512) && s->dim_n[0] * 4 >= 8192 / L) {
+        } else if ((L == 64 || L == 128 || L == 256 || L == 512) &&
+                   s->dim_n[0] * s->tile_lo_n * 4 >= 8192 / L) {
             s->variant = FFTW_AMD_K_RR;     /* two-stage register kernel, 8192/L sequences per tile */
             s->tile = (int)(8192 / L);
         }
@@ -660,7 +691,7 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     }
     /* A strided axis keeps tiles at least 8 wide so that global access stays
        in 128-byte segments; a contiguous axis may fill the tile by itself. */
-    contiguous = (iabs(ax.is) <= 2 && iabs(ax.os) <= 2);
+    contiguous = (iabs(ax.is) <= 2 && iabs(ax.os) <= 2) || ax.dense;
     lmax1 = contiguous ? FA_LMAX_SINGLE : FA_TILE_ELEMS / 8;
     /* powers of two above 1024 run faster as two register-kernel passes than
        as one LDS-sized pass (measured: 4096-point rows 0.8 TB/s vs ~5 TB/s per pass) */
@@ -768,6 +799,17 @@ static void build_c2c(plan *p) {
     }
 }
 
+/* passes a contiguous axis of length n needs (mirrors fa_emit_axis); 99 for
+   lengths that go through Rader / Bluestein */
+static int axis_pass_count(i64 n) {
+    i64 lens[FA_MAXPASS], lmax1 = FA_LMAX_SINGLE;
+    int k;
+    if (!fa_lds_able(n)) return 99;
+    if (n > 1024 && (n & (n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) lmax1 = 1024;
+    k = fa_factor_passes(n, FA_MAXPASS, lmax1, g_lmax_multi, lens);
+    return k ? k : 99;
+}
+
 /* r2c: last dim real -> half spectrum, then complex DFTs over the other dims
    on the half-spectrum array (reference rank_geq2_rdft2 A.c:10111-10282).
    p->dims[].is are strides of the REAL array (doubles), .os of the complex
@@ -784,7 +826,55 @@ static void build_r2c(plan *p) {
     memset(&ax, 0, sizeof(ax));
     if (collect_loops(p, p->dims, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
 
-    if (nl % 2 == 0 && nl >= 2) {
+    if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
+        (axis_pass_count(nl / 4) < axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
+        /* n = 4m: two complex DFTs of size m on (x[4j], x[4j+1]) and (x[4j+2], x[4j+3]),
+           then the radix-4 untangle -- the reference's rdft2-ct-dit/4 + hc2cfdft_4 plan,
+           chosen when m needs fewer passes than n/2 (n = 2^22: m = 2^20 is 1024 x 1024) */
+        i64 m = nl / 4, zts, lts[FA_MAXLOOPS + 1], total, rs = p->dims[r - 1].is;
+        int zbuf, nd, vloop;
+        fa_loc z;
+        fa_axis q_ax = ax, lay;
+        sdim d[FA_MAXLOOPS + 1];
+        fftw_amd_step_desc *s;
+        /* scratch [loops][v][m]: the vector index v rides as the innermost loop */
+        vloop = q_ax.nloops++;
+        q_ax.loops[vloop].n = 2;
+        q_ax.loops[vloop].is = 2 * rs;
+        q_ax.loops[vloop].os = 0;
+        lay = q_ax;
+        lay.is = 2;
+        lay.loops[vloop].is = 1;           /* the pair index is innermost: Z[k][v], like the input */
+        total = scratch_layout(&lay, m, &zts, lts);
+        zbuf = buf_acquire(p, total);
+        z.buf = zbuf; z.base = 0; z.im = 1;
+        q_ax.dense = (rs == 1);
+        q_ax.n = m;
+        q_ax.is = 4 * rs;
+        q_ax.os = zts;
+        q_ax.src = in;
+        q_ax.src.im = rs;
+        q_ax.dst = z;
+        for (j = 0; j < q_ax.nloops; ++j) q_ax.loops[j].os = lts[j];
+        fa_emit_axis(p, &q_ax);
+
+        s = new_step(p, FFTW_AMD_STEP_R2C_POST4);
+        s->src_buf = zbuf; s->src_base = 0; s->src_im = 1;
+        s->dst_buf = 1; s->dst_base = 0; s->dst_im = p->out_im;
+        s->is_l = zts;
+        s->os_l = p->dims[r - 1].os;
+        s->aux_n = nl;
+        s->aux_valid = lts[vloop];
+        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        nd = 0;
+        for (j = 0; j < ax.nloops; ++j) {
+            d[nd].n = ax.loops[j].n; d[nd].is = lts[j]; d[nd].os = ax.loops[j].os;
+            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+        }
+        step_set_dims(p, s, d, nd, -1);
+        p->est_flops += 20.0 * (double)m;
+        buf_release(p, zbuf);
+    } else if (nl % 2 == 0 && nl >= 2) {
         /* z[j] = x[2j] + i x[2j+1]; Z = DFT_{n/2}(z); untangle */
         i64 h = nl / 2, zts, lts[FA_MAXLOOPS], total;
         int zbuf, nd;
@@ -933,7 +1023,55 @@ static void build_c2r(plan *p) {
         if (collect_loops(&view, td, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
     }
 
-    if (nl % 2 == 0 && nl >= 2) {
+    if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
+        (axis_pass_count(nl / 4) < axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
+        /* transpose of the radix-4 r2c plan: tangle into two quarter-length
+           spectra, two backward complex DFTs of size m straight into the real array */
+        i64 m = nl / 4, zts, lts[FA_MAXLOOPS + 1], total, rs = p->dims[r - 1].os;
+        int zbuf, nd, vloop;
+        fa_loc z;
+        fa_axis q_ax = ax, lay;
+        sdim d[FA_MAXLOOPS + 1];
+        fftw_amd_step_desc *s;
+        vloop = q_ax.nloops++;
+        q_ax.loops[vloop].n = 2;
+        q_ax.loops[vloop].is = 0;
+        q_ax.loops[vloop].os = 2 * rs;
+        lay = q_ax;
+        lay.is = 2;
+        lay.loops[vloop].is = 1;
+        total = scratch_layout(&lay, m, &zts, lts);
+        zbuf = buf_acquire(p, total);
+        z.buf = zbuf; z.base = 0; z.im = 1;
+        q_ax.dense = (rs == 1);
+
+        s = new_step(p, FFTW_AMD_STEP_C2R_PRE4);
+        s->src_buf = cur.buf; s->src_base = cur.base; s->src_im = cur.im;
+        s->dst_buf = zbuf; s->dst_base = 0; s->dst_im = 1;
+        s->is_l = cdims[r - 1].is;
+        s->os_l = zts;
+        s->aux_n = nl;
+        s->aux_valid = lts[vloop];
+        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        nd = 0;
+        for (j = 0; j < ax.nloops; ++j) {
+            d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
+            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+        }
+        step_set_dims(p, s, d, nd, -1);
+
+        q_ax.n = m;
+        q_ax.is = zts;
+        q_ax.os = 4 * rs;
+        q_ax.src = z;
+        q_ax.dst = out;
+        q_ax.dst.im = rs;
+        q_ax.flags_in = FFTW_AMD_F_SWAP_IN;
+        q_ax.flags_out = FFTW_AMD_F_SWAP_OUT;
+        for (j = 0; j < q_ax.nloops; ++j) q_ax.loops[j].is = lts[j];
+        fa_emit_axis(p, &q_ax);
+        buf_release(p, zbuf);
+    } else if (nl % 2 == 0 && nl >= 2) {
         i64 h = nl / 2, zts, lts[FA_MAXLOOPS], total;
         int zbuf, nd;
         fa_loc z;
@@ -1332,6 +1470,8 @@ static const char *kind_name(int k) {
     case FFTW_AMD_STEP_C2R_PRE: return "c2r-tangle";
     case FFTW_AMD_STEP_RADER_MUL: return "rader-mul";
     case FFTW_AMD_STEP_HERM_EXPAND: return "herm-expand";
+    case FFTW_AMD_STEP_R2C_POST4: return "r2c-untangle4";
+    case FFTW_AMD_STEP_C2R_PRE4: return "c2r-tangle4";
     }
     return "?";
 }

@@ -75,6 +75,12 @@ typedef struct {
     int aux_buf;                  /* Rader: buffer holding x[0] per vector */
     long long aux_base;
     int variant;                  /* which kernel the executor launches (FFTW_AMD_K_*) */
+    /* optional inner component of the tile dim: the sequences of a tile are
+       (lo, hi) pairs, lo in [0, tile_lo_n) fastest; dims[0] describes hi.
+       Semantically just one more loop; it lets two interleaved vectors (radix-4
+       real transforms) share 16-byte-contiguous global accesses. */
+    int tile_lo_n;
+    long long tile_lo_is, tile_lo_os;
 } fftw_amd_step_desc;
 
 enum {
@@ -83,7 +89,9 @@ enum {
     FFTW_AMD_STEP_R2C_POST = 3, /* untangle half-length complex DFT into r2c output */
     FFTW_AMD_STEP_C2R_PRE = 4,  /* inverse of the above */
     FFTW_AMD_STEP_RADER_MUL = 5,/* Rader pointwise product and DC fix-ups */
-    FFTW_AMD_STEP_HERM_EXPAND = 6 /* half spectrum -> full Hermitian spectrum */
+    FFTW_AMD_STEP_HERM_EXPAND = 6,/* half spectrum -> full Hermitian spectrum */
+    FFTW_AMD_STEP_R2C_POST4 = 7,  /* radix-4 untangle: two quarter-length complex DFTs -> r2c output */
+    FFTW_AMD_STEP_C2R_PRE4 = 8    /* inverse of the above */
 };
 
 enum {

@@ -104,6 +104,11 @@ class Interp(object):
             if s.dst_buf < 2:
                 dbase += cs * dos[bd]
             dn[bd] = cn
+        if s.kind == fa.STEP_PASS and s.tile_lo_n > 1:     # inner tile component = one more loop
+            dn.append(s.tile_lo_n)
+            dis.append(s.tile_lo_is)
+            dos.append(s.tile_lo_os)
+            dtw.append(0)
         return dn, dis, dos, dtw, sbase, dbase
 
     def step(self, s, bufs, cs, cn):
@@ -206,6 +211,61 @@ class Interp(object):
                 kmm = np.where(ok, km, k)
                 _store(dst, doff + kmm * s.os_l, s.dst_im, s.flags, np.where(ok, zm, zk))
                 _store(dst, doff + k * s.os_l, s.dst_im, s.flags, zk)
+        elif s.kind in (fa.STEP_R2C_POST4, fa.STEP_C2R_PRE4):
+            n = s.aux_n
+            m = n // 4
+            vs = s.aux_valid
+            g = _grids([m // 2 + 1] + dn)
+            k, idx = g[0], g[1:]
+            soff = np.zeros_like(k) + sbase
+            doff = np.zeros_like(k) + dbase
+            for i, gi in enumerate(idx):
+                soff = soff + gi * dis[i]
+                doff = doff + gi * dos[i]
+            w = [None, self.tw2(s, k), self.tw2(s, 2 * k), self.tw2(s, 3 * k)]
+            if s.kind == fa.STEP_R2C_POST4:
+                km = np.where(k == 0, 0, m - k)
+                T = []
+                for v in range(2):
+                    zk = _load(src, soff + v * vs + k * s.is_l, s.src_im, 0)
+                    zm = _load(src, soff + v * vs + km * s.is_l, s.src_im, 0)
+                    T.append(0.5 * (zk + np.conj(zm)))
+                    T.append(-0.5j * (zk - np.conj(zm)))
+                T = [T[0]] + [T[i] * np.conj(w[i]) for i in (1, 2, 3)]
+                y0 = T[0] + T[1] + T[2] + T[3]
+                y1 = T[0] - 1j * T[1] - T[2] + 1j * T[3]
+                y2 = np.conj(T[0] - T[1] + T[2] - T[3])
+                y3 = np.conj(T[0] + 1j * T[1] - T[2] - 1j * T[3])
+                y0 = np.where(k == 0, y0.real + 0j, y0)
+                y2 = np.where(k == 0, y2.real + 0j, y2)
+                # duplicates first, the canonical writers last
+                _store(dst, doff + (m - k) * s.os_l, s.dst_im, s.flags, np.where((k == 0), y1, y3))
+                _store(dst, doff + (2 * m - k) * s.os_l, s.dst_im, s.flags, y2)
+                _store(dst, doff + (k + m) * s.os_l, s.dst_im, s.flags, y1)
+                _store(dst, doff + k * s.os_l, s.dst_im, s.flags, y0)
+            else:
+                Yk = _load(src, soff + k * s.is_l, s.src_im, 0)
+                Ykm = _load(src, soff + (k + m) * s.is_l, s.src_im, 0)
+                Y2 = _load(src, soff + (2 * m - k) * s.is_l, s.src_im, 0)
+                Y1 = _load(src, soff + (m - k) * s.is_l, s.src_im, 0)
+                Yk = np.where(k == 0, Yk.real + 0j, Yk)
+                Y2 = np.where(k == 0, Y2.real + 0j, Y2)
+
+                def comb(A, B, Cc, Dc, w1, w2, w3):
+                    S0 = A + B + Cc + Dc
+                    S1 = A + 1j * B - Cc - 1j * Dc
+                    S2 = A - B + Cc - Dc
+                    S3 = A - 1j * B - Cc + 1j * Dc
+                    return S0 + 1j * (S1 * w1), S2 * w2 + 1j * (S3 * w3)
+                z0, z1 = comb(Yk, Ykm, np.conj(Y2), np.conj(Y1), w[1], w[2], w[3])
+                z0m, z1m = comb(Y1, Y2, np.conj(Ykm), np.conj(Yk), 1j * np.conj(w[1]), -np.conj(w[2]),
+                                -1j * np.conj(w[3]))
+                ok = (k != 0) & (2 * k != m)
+                km = np.where(ok, m - k, k)
+                _store(dst, doff + km * s.os_l, s.dst_im, s.flags, np.where(ok, z0m, z0))
+                _store(dst, doff + vs + km * s.os_l, s.dst_im, s.flags, np.where(ok, z1m, z1))
+                _store(dst, doff + k * s.os_l, s.dst_im, s.flags, z0)
+                _store(dst, doff + vs + k * s.os_l, s.dst_im, s.flags, z1)
         elif s.kind == fa.STEP_RADER_MUL:
             pm1 = s.aux_n
             nvec = int(np.prod(dn)) if dn else 1

@@ -160,6 +160,47 @@ def test_r2c_c2r_nd(torch_dev, shape):
     assert np.array_equal(yin.cpu().numpy(), ref)              # scratch keeps the input intact
 
 
+def test_radix4_real_transforms_forced(torch_dev, monkeypatch):
+    """the rdft2-ct-dit/4 style plan (two quarter-length complex DFTs + radix-4 untangle)
+    on sizes where the planner would not pick it by itself"""
+    torch, dev = torch_dev
+    monkeypatch.setenv("FFTW_AMD_FORCE_RADIX4", "1")
+    rng = np.random.default_rng(44)
+    for n in (8, 12, 20, 100, 1000, 4096, 40000, 1 << 16):
+        b = 3
+        x = rrand(rng, b, n)
+        xd = torch.from_numpy(x).to(dev)
+        yd = torch.zeros((b, n // 2 + 1), dtype=torch.complex128, device=dev)
+        p = fa.plan_many_dft_r2c(1, [n], b, xd, None, 1, n, yd, None, 1, n // 2 + 1)
+        assert "untangle4" in p.sprint()
+        p.execute()
+        torch.cuda.synchronize()
+        ref = oracle_r2c(x, (n,), b).reshape(b, n // 2 + 1)
+        assert aerror(yd.cpu().numpy(), ref) < TOL, n
+        yin = torch.from_numpy(ref).to(dev)
+        zd = torch.zeros((b, n), dtype=torch.float64, device=dev)
+        p = fa.plan_many_dft_c2r(1, [n], b, yin, None, 1, n // 2 + 1, zd, None, 1, n)
+        assert "tangle4" in p.sprint()
+        p.execute()
+        torch.cuda.synchronize()
+        assert aerror(zd.cpu().numpy(), x * n) < TOL, n
+
+
+@pytest.mark.parametrize("n", [64, 128, 256, 512, 1024, 2048, 4096, 8192, 1 << 14, 1 << 18, 1 << 21])
+def test_register_kernels_wide_batches(torch_dev, n):
+    """every register-kernel length with batches wide enough to fill their tiles,
+    including ragged tile tails, forward / backward / in place"""
+    rng = np.random.default_rng(n + 1)
+    for b in ((200, 77) if n <= 4096 else (5,)):
+        for sign in (-1, 1):
+            x = crand(rng, b, n)
+            y = gpu_c2c(torch_dev, x, (n,), b, sign)
+            assert aerror(y, oracle_dft(x, (n,), b, sign).reshape(b, n)) < TOL
+    x = crand(rng, 9, n)
+    y = gpu_c2c(torch_dev, x, (n,), 9, -1, inplace=True)
+    assert aerror(y, oracle_dft(x, (n,), 9).reshape(9, n)) < TOL
+
+
 def test_layouts_inplace_embed_split_guru_newarray(torch_dev):
     torch, dev = torch_dev
     rng = np.random.default_rng(9)

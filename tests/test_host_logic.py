@@ -142,6 +142,40 @@ def test_planner_r2c_inplace_padded_and_nd():
         assert aerror(z, x * nn) < TOL
 
 
+def test_planner_radix4_real_transforms(monkeypatch):
+    """n = 4m: two quarter-length complex DFTs + radix-4 untangle (the reference's
+    rdft2-ct-dit/4 + hc2cfdft_4 plan); chosen by itself when m
+    needs fewer passes than n/2 (n = 4096 here, n = 2^22 on the GPU tier), forced for the rest"""
+    x = np.zeros(4096)
+    assert "untangle4" in fa.plan_dft_r2c_1d(4096, x, np.zeros(2049, dtype=complex)).sprint()
+    assert "untangle4" in fa.plan_dft_r2c_1d(1 << 22, np.zeros(8), np.zeros(8, dtype=complex)).sprint()
+    monkeypatch.setenv("FFTW_AMD_FORCE_RADIX4", "1")
+    for n in (8, 12, 20, 36, 64, 100, 1000, 4096, 40000):
+        for b in (1, 3):
+            x = rrand(rng, b, n)
+            y = np.zeros((b, n // 2 + 1), dtype=complex)
+            p = fa.plan_many_dft_r2c(1, [n], b, x, None, 1, n, y, None, 1, n // 2 + 1)
+            assert "untangle4" in p.sprint()
+            run_plan_on_host(p, x, y)
+            ref = oracle_r2c(x, (n,), b).reshape(b, n // 2 + 1)
+            assert aerror(y, ref) < TOL, n
+            yy = ref.copy()
+            yy[:, 0] += 0.25j
+            yy[:, -1] += 0.5j * (n % 2 == 0)
+            z = np.zeros((b, n))
+            p = fa.plan_many_dft_c2r(1, [n], b, yy, None, 1, n // 2 + 1, z, None, 1, n)
+            assert "tangle4" in p.sprint()
+            run_plan_on_host(p, yy, z)
+            assert aerror(z, oracle_c2r(ref, (n,), b).reshape(b, n)) < TOL, n
+    for shape in [(4, 8), (6, 16), (5, 6, 12)]:
+        nn, hs = int(np.prod(shape)), shape[:-1] + (shape[-1] // 2 + 1,)
+        x = rrand(rng, 2, *shape)
+        y = np.zeros((2,) + hs, dtype=complex)
+        p = fa.plan_many_dft_r2c(len(shape), list(shape), 2, x, None, 1, nn, y, None, 1, int(np.prod(hs)))
+        run_plan_on_host(p, x, y)
+        assert aerror(y, oracle_r2c(x, shape, 2).reshape(y.shape)) < TOL
+
+
 def test_guru_and_split_interfaces():
     # guru: transform dim of 30 with stride 7 (complex), two howmany dims
     n, h0, h1 = 30, 3, 2
