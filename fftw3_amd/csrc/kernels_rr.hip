@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "pass1024.hpp"
 #include "passrr.hpp"
+#include "pass3s.hpp"
 
 template <int R1, int R2, bool IN_T, bool OUT_T, int TW>
 static void launch_rr_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
@@ -98,4 +99,56 @@ int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *con
     case 512: return dispatch_rr<32, 16>(pa, grid, st, in_t, out_t, tw);
     }
     return 1;
+}
+
+template <int R1>
+static void launch_3s(const P3SArgs &pa, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    const size_t lds = P3SGeom<R1>::lds_doubles * sizeof(double);
+    if (!attr_done) {
+        FA_CHECK(hipFuncSetAttribute((const void *)pass3s_kernel<R1>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pass3s_kernel<R1>), grid, dim3(256), lds, st, pa);
+}
+
+/* contiguous rows of 2048 / 4096 in one pass; 1 = not applicable */
+int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                     i64 cs, i64 cn, hipStream_t st) {
+    P3SArgs pa;
+    int bd = d->batch_dim, T;
+    i64 sbase = d->src_base, dbase = d->dst_base;
+    if ((d->L != 2048 && d->L != 4096) || d->src_im != 1 || d->dst_im != 1 || d->tw_n ||
+        d->is_l != 2 || d->os_l != 2 || d->tile_lo_n > 1 ||
+        (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
+        return 1;
+    T = 8192 / d->L;
+    for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+        pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+        pa.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+        pa.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+    }
+    if (bd >= 0) {
+        sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+        dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+        pa.dn[bd] = cn;
+    }
+    pa.src = bufs[d->src_buf] + sbase;
+    pa.dst = bufs[d->dst_buf] + dbase;
+    if (((uintptr_t)pa.src % 16) || ((uintptr_t)pa.dst % 16)) return 1;
+    for (int i = 0; i < d->ndims; ++i)
+        if ((pa.dis[i] % 2) || (pa.dos[i] % 2)) return 1;
+    pa.wL = (const cplx *)tables[d->table];
+    pa.ndims = d->ndims;
+    pa.flags = d->flags;
+    pa.ntiles = (pa.dn[0] + T - 1) / T;
+    i64 nblocks = pa.ntiles;
+    for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
+    if (nblocks <= 0) return 0;
+    if (nblocks > 0x7fffffffLL) return 1;
+    dim3 grid((unsigned)nblocks, 1, 1);
+    if (d->L == 2048) launch_3s<8>(pa, grid, st);
+    else launch_3s<16>(pa, grid, st);
+    return 0;
 }

@@ -386,6 +386,9 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
         if (L == 1024) {
             s->variant = FFTW_AMD_K_P1024;  /* register-resident radix-32x32, 8 sequences per tile */
             s->tile = 8;
+        } else if ((L == 2048 || L == 4096) && is_l == 2 && os_l == 2 && tw_n == 0 && s->tile_lo_n == 1) {
+            s->variant = FFTW_AMD_K_R3;     /* three-stage register kernel, whole contiguous rows */
+            s->tile = (int)(8192 / L);
         } else if ((L == 64 || L == 128 || L == 256 || L == 512) &&
                    s->dim_n[0] * s->tile_lo_n * 4 >= 8192 / L) {
             s->variant = FFTW_AMD_K_RR;     /* two-stage register kernel, 8192/L sequences per tile */
@@ -696,7 +699,14 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     /* powers of two above 1024 run faster as two register-kernel passes than
        as one LDS-sized pass (measured: 4096-point rows 0.8 TB/s vs ~5 TB/s per pass) */
     if (contiguous && ax.n > 1024 && (ax.n & (ax.n - 1)) == 0 && ax.nloops > 0 &&
-        !getenv("FFTW_AMD_NO_TUNED")) lmax1 = 1024;
+        !getenv("FFTW_AMD_NO_TUNED")) {
+        /* ... except contiguous rows of 2048 / 4096: the three-stage kernel does them in one */
+        int rows3s = (ax.n == 2048 || ax.n == 4096) && iabs(ax.is) == 2 && iabs(ax.os) == 2 &&
+                     ax.src.im == 1 && ax.dst.im == 1 &&
+                     !((ax.flags_in | ax.flags_out) & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT)) &&
+                     !getenv("FFTW_AMD_NO_3S");
+        if (!rows3s) lmax1 = 1024;
+    }
     if (ax.nloops == 0 && !contiguous) lmax1 = FA_LMAX_SINGLE;
     k = fa_factor_passes(ax.n, FA_MAXPASS, lmax1, contiguous ? g_lmax_multi : FA_TILE_ELEMS / 8, lens);
     if (k == 0) {
@@ -805,6 +815,7 @@ static int axis_pass_count(i64 n) {
     i64 lens[FA_MAXPASS], lmax1 = FA_LMAX_SINGLE;
     int k;
     if (!fa_lds_able(n)) return 99;
+    /* (the radix-4 real plans feed strided pair data: the 3-stage row kernel does not apply) */
     if (n > 1024 && (n & (n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) lmax1 = 1024;
     k = fa_factor_passes(n, FA_MAXPASS, lmax1, g_lmax_multi, lens);
     return k ? k : 99;

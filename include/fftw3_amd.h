@@ -97,7 +97,8 @@ enum {
 enum {
     FFTW_AMD_K_GENERIC = 0,     /* runtime-radix LDS kernel */
     FFTW_AMD_K_P1024 = 1,       /* register-resident radix-32x32 kernel, tile of 8 */
-    FFTW_AMD_K_RR = 2           /* register-resident two-stage kernel, L = 64..512, tile of 8192/L */
+    FFTW_AMD_K_RR = 2,          /* register-resident two-stage kernel, L = 64..512, tile of 8192/L */
+    FFTW_AMD_K_R3 = 3           /* register-resident three-stage kernel for contiguous rows of 2048 / 4096 */
 };
 
 enum {
