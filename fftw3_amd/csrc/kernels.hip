@@ -19,6 +19,7 @@
 #include "pass1024.hpp"
 #include "stream1024.hpp"
 #include "fused1024.hpp"
+#include "mixed1024.hpp"
 
 /* ------------------------------------------------------------------------ */
 /* generic LDS pass kernel (runtime radices)                                 */
@@ -991,5 +992,27 @@ extern "C" int fa_hip_launch_fused1024(const double *in, double *out, double *sc
     { const char *e = getenv("FFTW_AMD_FUSED_DBG"); if (e) a.flags |= atoi(e) << 24; }
     FA_CHECK(hipMemsetAsync(ctrl, 0, sizeof(int) * (size_t)(2 * batch + 16), st));
     hipLaunchKernelGGL(fused1024_kernel, dim3(2 * ncu), dim3(256), lds, st, a);
+    return 0;
+}
+
+extern "C" int fa_hip_launch_mixed1024(const double *in, double *out, double *slot_w, const double *slot_r,
+                                       long long in_bs, long long out_bs, int n1, int n2, int flags,
+                                       const void *w1024, const void *tw_lo, const void *tw_hi, int tw_shift,
+                                       void *stream) {
+    static bool attr_done = false;
+    const size_t lds = FA_P1024_LDS_DOUBLES * sizeof(double);
+    if (!attr_done) {
+        FA_CHECK(hipFuncSetAttribute((const void *)mixed1024_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    Mixed1024Args a;
+    a.in = in; a.out = out; a.slot_w = slot_w; a.slot_r = slot_r;
+    a.in_bs = in_bs; a.out_bs = out_bs; a.n1 = n1; a.n2 = n2;
+    a.w1024 = (const cplx *)w1024; a.tw_lo = (const cplx *)tw_lo; a.tw_hi = (const cplx *)tw_hi;
+    a.tw_shift = tw_shift; a.flags = flags;
+    int blocks = (n1 + n2) * 128;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL(mixed1024_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
     return 0;
 }

@@ -26,6 +26,7 @@ typedef struct fftw_plan_s plan;
 static size_t g_chunk_bytes = (size_t)1 << 30;
 static i64 g_lmax_multi = 1024;
 static int g_pipeline = 1;
+static int g_mixed = 0, g_mixed_chunk = 4;
 static int g_fused = 0, g_fused_lag = 5, g_fused_slots = 10;   /* opt-in: FFTW_AMD_FUSED=1 */
 
 void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : ((size_t)1 << 30); }
@@ -44,6 +45,10 @@ plan *fa_plan_new(void) {
     if (e && atoll(e) > 0) g_chunk_bytes = (size_t)atoll(e);
     e = getenv("FFTW_AMD_FUSED");
     if (e) g_fused = atoi(e);
+    e = getenv("FFTW_AMD_MIXED");
+    if (e) g_mixed = atoi(e);
+    e = getenv("FFTW_AMD_MIXED_CHUNK");
+    if (e && atoi(e) >= 1) g_mixed_chunk = atoi(e);
     e = getenv("FFTW_AMD_FUSED_SLOTS");
     if (e && atoi(e) >= 2) g_fused_slots = atoi(e);
     e = getenv("FFTW_AMD_FUSED_LAG");
@@ -1244,14 +1249,20 @@ int fa_device_init(plan *p) {
         }
     }
     /* batched contiguous n = 2^20: both passes in one persistent launch */
-    if (g_fused && p->type == FA_C2C && p->rank == 1 && p->dims[0].n == ((i64)1 << 20) &&
+    if ((g_fused || g_mixed) && p->type == FA_C2C && p->rank == 1 && p->dims[0].n == ((i64)1 << 20) &&
         p->dims[0].is == 2 && p->dims[0].os == 2 && p->hrank == 1 && p->nsteps == 2 &&
         p->in_im == 1 && p->out_im == 1 && p->batch >= 8 && p->batch < ((i64)1 << 28) &&
         p->steps[0].variant == FFTW_AMD_K_P1024 && p->steps[1].variant == FFTW_AMD_K_P1024 &&
         (p->hdims[0].is % 2) == 0 && (p->hdims[0].os % 2) == 0) {
+        if (g_mixed) {
+            p->mixed = 1;
+            p->mixed_chunk = g_mixed_chunk;
+            if (p->mixed_chunk > p->batch) p->mixed_chunk = (int)p->batch;
+        }
         p->fused = 1;
         p->fused_lag = g_fused_lag;
         p->fused_slots = g_fused_slots > g_fused_lag ? g_fused_slots : g_fused_lag + 3;
+        if (p->mixed && p->fused_slots < 2 * p->mixed_chunk) p->fused_slots = 2 * p->mixed_chunk;
         p->fused_scratch = (double *)fa_hip_malloc((size_t)p->fused_slots * ((size_t)1 << 20) * 16);
         p->fused_ctrl = (int *)fa_hip_malloc(sizeof(int) * (size_t)(2 * p->batch + 16));
         p->fused_err_host = (int *)fa_hip_host_malloc(sizeof(int) * 4);
@@ -1348,7 +1359,34 @@ void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
         fprintf(stderr, "fftw3_amd: fused kernel reported a synchronisation timeout (%d)\n", p->fused_err_host[0]);
         abort();
     }
-    if (p->fused && fa_hip_is_device_ptr(ri) && fa_hip_is_device_ptr(ro) && ii == ri + 1 && io == ro + 1) {
+    if (p->mixed && fa_hip_is_device_ptr(ri) && fa_hip_is_device_ptr(ro) && ii == ri + 1 && io == ro + 1) {
+        const fftw_amd_step_desc *s1 = &p->steps[1];
+        const i64 C = p->mixed_chunk, nch = (p->batch + C - 1) / C, slot_doubles = C * ((i64)2 << 20);
+        int flags = (p->sign > 0) ? (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT) : 0;
+        void *e0 = NULL, *e1 = NULL;
+        i64 k;
+        if (g_prof_ms) { e0 = fa_hip_event_create(); e1 = fa_hip_event_create(); fa_hip_event_record(e0, p->stream); }
+        for (k = 0; k <= nch; ++k) {
+            /* launch k: pass 1 of chunk k, pass 2 of chunk k-1 */
+            int n1 = k < nch ? (int)((p->batch - k * C < C) ? p->batch - k * C : C) : 0;
+            int n2 = k >= 1 ? (int)((p->batch - (k - 1) * C < C) ? p->batch - (k - 1) * C : C) : 0;
+            fa_hip_launch_mixed1024(bufs[0] + k * C * p->hdims[0].is, bufs[1] + (k - 1) * C * p->hdims[0].os,
+                                    p->fused_scratch + (k & 1) * slot_doubles,
+                                    p->fused_scratch + ((k + 1) & 1) * slot_doubles,
+                                    p->hdims[0].is, p->hdims[0].os, n1, n2, flags,
+                                    tabs[s1->table], tabs[s1->tw_lo], tabs[s1->tw_hi], s1->tw_shift, p->stream);
+        }
+        if (g_prof_ms) {
+            fa_hip_event_record(e1, p->stream);
+            fa_hip_stream_sync(p->stream);
+            g_prof_ms[0] += (double)fa_hip_event_elapsed_ms(e0, e1);
+            g_prof_launches[0] += nch + 1;
+            fa_hip_event_destroy(e0);
+            fa_hip_event_destroy(e1);
+        }
+        return;
+    }
+    if (p->fused && !p->mixed && fa_hip_is_device_ptr(ri) && fa_hip_is_device_ptr(ro) && ii == ri + 1 && io == ro + 1) {
         const fftw_amd_step_desc *s1 = &p->steps[1];
         void *e0 = NULL, *e1 = NULL;
         int flags = (p->sign > 0) ? (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT) : 0;
