@@ -119,6 +119,11 @@ _sig("fftw_plan_guru64_dft_c2r", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.PO
      _vp, _vp, C.c_uint)
 _sig("fftw_destroy_plan", None, _vp)
 _sig("fftw_cleanup", None)
+_sig("fftw_forget_wisdom", None)
+_sig("fftw_export_wisdom_to_string", _vp)
+_sig("fftw_import_wisdom_from_string", C.c_int, C.c_char_p)
+_sig("fftw_export_wisdom_to_filename", C.c_int, C.c_char_p)
+_sig("fftw_import_wisdom_from_filename", C.c_int, C.c_char_p)
 _sig("fftw_malloc", _vp, C.c_size_t)
 _sig("fftw_free", None, _vp)
 _sig("fftw_sprint_plan", _vp, _vp)
@@ -397,3 +402,18 @@ def factor_passes(n, max_passes=4):
 
 def set_chunk_bytes(nbytes):
     lib.fftw_amd_set_chunk_bytes(nbytes)
+
+
+def export_wisdom_to_string():
+    p = lib.fftw_export_wisdom_to_string()
+    s = C.string_at(p).decode()
+    _libc_free(p)
+    return s
+
+
+def import_wisdom_from_string(s):
+    return lib.fftw_import_wisdom_from_string(s.encode())
+
+
+def forget_wisdom():
+    lib.fftw_forget_wisdom()

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "fa_plan.h"
 #include "fa_hip.h"
 
@@ -16,6 +17,76 @@ typedef struct fftw_plan_s plan;
 const char fftw_version[] = "fftw3-amd-0.1 (MI355X/gfx950 HIP executor, FFTW 3.3 API)";
 const char fftw_cc[] = "hipcc --offload-arch=gfx950";
 const char fftw_codelet_optim[] = "";
+
+
+/* ------------------------------------------------------------- wisdom */
+/* What the reference's planner learns by timing (ifftw_mkplan + wisdom hash
+   table, fftw/fftw_api.c:15300-15426, 14829-14838) becomes here: which launch
+   configuration is fastest for a problem -- scratch chunk size, the two-stream
+   chunk pipeline, the longest sub-transform of a multi-pass split, generic
+   kernel tile size.  FFTW_ESTIMATE takes the static defaults; any other flag
+   times the candidates on the device (overwriting the arrays, as FFTW_MEASURE
+   does in the reference: A.c:18604) and records the winner as wisdom, which the
+   wisdom export / import calls move between processes as text. */
+typedef struct wis_s {
+    struct wis_s *next;
+    char key[320];
+    fa_cfg cfg;
+    double ms;
+} wis_entry;
+static wis_entry *g_wisdom = NULL;
+
+static void wis_key(const plan *p, char *key, size_t cap) {
+    size_t len = 0;
+    int i;
+    len += (size_t)snprintf(key + len, cap - len, "t%d s%d r%d", p->type, p->sign, p->rank);
+    for (i = 0; i < p->rank && len < cap; ++i)
+        len += (size_t)snprintf(key + len, cap - len, " %lld:%lld:%lld", p->dims[i].n, p->dims[i].is, p->dims[i].os);
+    len += (size_t)snprintf(key + len, cap - len, " h%d", p->hrank);
+    for (i = 0; i < p->hrank && len < cap; ++i)
+        len += (size_t)snprintf(key + len, cap - len, " %lld:%lld:%lld", p->hdims[i].n, p->hdims[i].is, p->hdims[i].os);
+    snprintf(key + len, cap > len ? cap - len : 0, " i%lld o%lld p%d", p->in_im, p->out_im, p->inplace);
+}
+
+static wis_entry *wis_find(const char *key) {
+    wis_entry *w;
+    for (w = g_wisdom; w; w = w->next) if (!strcmp(w->key, key)) return w;
+    return NULL;
+}
+
+static void wis_put(const char *key, fa_cfg cfg, double ms) {
+    wis_entry *w = wis_find(key);
+    if (!w) {
+        w = (wis_entry *)calloc(1, sizeof(*w));
+        if (!w) return;
+        snprintf(w->key, sizeof(w->key), "%s", key);
+        w->next = g_wisdom;
+        g_wisdom = w;
+    }
+    w->cfg = cfg;
+    w->ms = ms;
+}
+
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+
+/* copy the problem description of `p` into a fresh plan with configuration c */
+static plan *clone_problem(const plan *p, fa_cfg c) {
+    plan *q = fa_plan_new();
+    int i;
+    if (!q) return NULL;
+    q->type = p->type; q->sign = p->sign; q->flags = p->flags;
+    q->rank = p->rank; q->hrank = p->hrank;
+    for (i = 0; i < p->rank; ++i) q->dims[i] = p->dims[i];
+    for (i = 0; i < p->hrank; ++i) q->hdims[i] = p->hdims[i];
+    q->in_im = p->in_im; q->out_im = p->out_im;
+    q->single_chunk = p->single_chunk;
+    q->cfg = c;
+    return q;
+}
 
 /* ------------------------------------------------------------ helpers */
 
@@ -58,6 +129,52 @@ static plan *finish(plan *p, double *ri, double *ii, double *ro, double *io) {
     }
     for (i = 0; i < p->hrank; ++i) cnt *= p->hdims[i].n;
     p->out_written = (p->type == FA_C2R) ? cnt : 2 * cnt;
+    {
+        char key[320];
+        wis_entry *w;
+        wis_key(p, key, sizeof(key));
+        w = wis_find(key);
+        if (w) {
+            p->cfg = w->cfg;
+        } else if (p->flags & FFTW_WISDOM_ONLY) {
+            fa_plan_free(p);               /* reference: NULL when no wisdom applies (fftw3.h FFTW_WISDOM_ONLY) */
+            return NULL;
+        } else if (!(p->flags & FFTW_ESTIMATE) && ri && ro && fa_hip_device_count() > 0) {
+            /* FFTW_MEASURE / PATIENT / EXHAUSTIVE: time candidate configurations on the device */
+            static const size_t chunks[] = { (size_t)256 << 20, (size_t)1 << 30, (size_t)4 << 30 };
+            fa_cfg best = p->cfg, c;
+            double best_ms = -1.0;
+            int ci, pi, li, st, nl = (p->flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1;
+            for (ci = 0; ci < 3; ++ci)
+                for (pi = 0; pi < 2; ++pi)
+                    for (li = 0; li < nl; ++li)
+                        for (st = 0; st < nl; ++st) {
+                            plan *q;
+                            double t0, dt;
+                            c = p->cfg;
+                            c.chunk_bytes = chunks[ci];
+                            c.pipeline = pi;
+                            c.lmax_multi = li ? 512 : 1024;
+                            c.small_tiles = st;
+                            q = clone_problem(p, c);
+                            if (!q || fa_build(q)) { fa_plan_free(q); continue; }
+                            q->ri = ri; q->ii = ii; q->ro = ro; q->io = io;
+                            q->in_lo = p->in_lo; q->in_hi = p->in_hi; q->out_lo = p->out_lo; q->out_hi = p->out_hi;
+                            q->out_written = p->out_written;
+                            fa_run(q, ri, ii, ro, io);          /* warm-up, device init */
+                            fa_hip_stream_sync(q->stream);
+                            t0 = now_ms();
+                            fa_run(q, ri, ii, ro, io);
+                            fa_run(q, ri, ii, ro, io);
+                            fa_hip_stream_sync(q->stream);
+                            dt = 0.5 * (now_ms() - t0);
+                            if (best_ms < 0 || dt < best_ms) { best_ms = dt; best = c; }
+                            fa_plan_free(q);
+                        }
+            p->cfg = best;
+            wis_put(key, best, best_ms);
+        }
+    }
     if (fa_build(p)) { fa_plan_free(p); return NULL; }
     return p;
 }
@@ -461,44 +578,127 @@ void fftw_execute_split_dft_c2r(const fftw_plan p, double *ri, double *ii, doubl
 /* NULL-safe like the reference (fftw/fftw_api.c:409-410) */
 void fftw_destroy_plan(fftw_plan p) { fa_plan_free(p); }
 
-/* There is no global planner state to drop: plans own their tables. */
-void fftw_cleanup(void) {}
-void fftw_forget_wisdom(void) {}
+/* The only global planner state is the wisdom list (below); plans own their tables. */
 void fftw_set_timelimit(double t) { (void)t; }
 void fftw_plan_with_nthreads(int nthreads) { (void)nthreads; }
 int  fftw_init_threads(void) { return 1; }
 void fftw_cleanup_threads(void) {}
 void fftw_make_planner_thread_safe(void) {}
 
-/* ---- wisdom: the static planner has nothing to remember; the calls succeed
-   with an empty record so that callers which save/restore wisdom keep working */
-static const char wisdom_text[] = "(fftw3_amd_wisdom)\n";
+/* ---- wisdom: text records "(key) chunk pipeline lmax small ms", one per problem */
+void fftw_forget_wisdom(void) {
+    while (g_wisdom) { wis_entry *n = g_wisdom->next; free(g_wisdom); g_wisdom = n; }
+}
+void fftw_cleanup(void) { fftw_forget_wisdom(); }   /* plans stay valid, like the reference (A.c:411-418) */
+
 char *fftw_export_wisdom_to_string(void) {
-    char *s = (char *)malloc(sizeof(wisdom_text));
-    if (s) memcpy(s, wisdom_text, sizeof(wisdom_text));
+    size_t cap = 64, len = 0;
+    wis_entry *w;
+    char *s;
+    for (w = g_wisdom; w; w = w->next) cap += strlen(w->key) + 96;
+    s = (char *)malloc(cap);
+    if (!s) return NULL;
+    len += (size_t)snprintf(s + len, cap - len, "(fftw3_amd_wisdom-1\n");
+    for (w = g_wisdom; w; w = w->next)
+        len += (size_t)snprintf(s + len, cap - len, "  (%s) %zu %d %d %d %.6f\n", w->key, w->cfg.chunk_bytes,
+                                w->cfg.pipeline, w->cfg.lmax_multi, w->cfg.small_tiles, w->ms);
+    snprintf(s + len, cap - len, ")\n");
     return s;
 }
-void fftw_export_wisdom_to_file(FILE *f) { fputs(wisdom_text, f); }
+void fftw_export_wisdom_to_file(FILE *f) {
+    char *s = fftw_export_wisdom_to_string();
+    if (s) { fputs(s, f); free(s); }
+}
 int fftw_export_wisdom_to_filename(const char *filename) {
     FILE *f = fopen(filename, "w");
     if (!f) return 0;
-    fputs(wisdom_text, f);
+    fftw_export_wisdom_to_file(f);
     return fclose(f) == 0;
 }
-void fftw_export_wisdom(fftw_write_char_func w, void *data) {
-    const char *c;
-    for (c = wisdom_text; *c; ++c) w(*c, data);
+void fftw_export_wisdom(fftw_write_char_func wr, void *data) {
+    char *s = fftw_export_wisdom_to_string(), *c;
+    if (!s) return;
+    for (c = s; *c; ++c) wr(*c, data);
+    free(s);
 }
-int fftw_import_system_wisdom(void) { return 0; }
+
+/* transactional like the reference (old wisdom survives a parse error, A.c:15577-15581) */
+int fftw_import_wisdom_from_string(const char *input) {
+    const char *c;
+    wis_entry *staged = NULL, *w;
+    int ok = 1;
+    if (!input || strncmp(input, "(fftw3_amd_wisdom-1", 19)) return 0;
+    c = input + 19;
+    for (;;) {
+        char key[320];
+        size_t chunk;
+        int pipe, lmax, small, n = 0;
+        double ms;
+        const char *o, *e;
+        while (*c == ' ' || *c == '\n' || *c == '\t' || *c == '\r') ++c;
+        if (*c == ')') break;                       /* end of list */
+        if (*c != '(') { ok = 0; break; }
+        o = c + 1;
+        e = strchr(o, ')');
+        if (!e || (size_t)(e - o) >= sizeof(key)) { ok = 0; break; }
+        memcpy(key, o, (size_t)(e - o));
+        key[e - o] = 0;
+        if (sscanf(e + 1, " %zu %d %d %d %lf%n", &chunk, &pipe, &lmax, &small, &ms, &n) != 5) { ok = 0; break; }
+        if (chunk < ((size_t)1 << 16) || lmax < 16 || lmax > 1024) { ok = 0; break; }
+        w = (wis_entry *)calloc(1, sizeof(*w));
+        if (!w) { ok = 0; break; }
+        snprintf(w->key, sizeof(w->key), "%s", key);
+        w->cfg.chunk_bytes = chunk; w->cfg.pipeline = pipe != 0; w->cfg.lmax_multi = lmax; w->cfg.small_tiles = small != 0;
+        w->ms = ms;
+        w->next = staged;
+        staged = w;
+        c = e + 1 + n;
+    }
+    while (staged) {
+        w = staged;
+        staged = staged->next;
+        if (ok) wis_put(w->key, w->cfg, w->ms);
+        free(w);
+    }
+    return ok;
+}
+int fftw_import_wisdom_from_file(FILE *f) {
+    size_t cap = 4096, len = 0, n;
+    char *buf = (char *)malloc(cap);
+    int ok;
+    if (!buf) return 0;
+    while ((n = fread(buf + len, 1, cap - len - 1, f)) > 0) {
+        len += n;
+        if (len + 1 >= cap) { cap *= 2; buf = (char *)realloc(buf, cap); if (!buf) return 0; }
+    }
+    buf[len] = 0;
+    ok = fftw_import_wisdom_from_string(buf);
+    free(buf);
+    return ok;
+}
 int fftw_import_wisdom_from_filename(const char *filename) {
     FILE *f = fopen(filename, "r");
+    int ok;
     if (!f) return 0;
+    ok = fftw_import_wisdom_from_file(f);
     fclose(f);
-    return 1;
+    return ok;
 }
-int fftw_import_wisdom_from_file(FILE *f) { (void)f; return 1; }
-int fftw_import_wisdom_from_string(const char *s) { return s != NULL; }
-int fftw_import_wisdom(fftw_read_char_func r, void *data) { (void)r; (void)data; return 1; }
+int fftw_import_system_wisdom(void) { return fftw_import_wisdom_from_filename("/etc/fftw/wisdom_amd"); }
+int fftw_import_wisdom(fftw_read_char_func rd, void *data) {
+    size_t cap = 4096, len = 0;
+    char *buf = (char *)malloc(cap);
+    int ch, ok;
+    if (!buf) return 0;
+    while ((ch = rd(data)) != EOF && ch > 0) {
+        buf[len++] = (char)ch;
+        if (len + 1 >= cap) { cap *= 2; buf = (char *)realloc(buf, cap); if (!buf) return 0; }
+    }
+    buf[len] = 0;
+    ok = fftw_import_wisdom_from_string(buf);
+    free(buf);
+    return ok;
+}
 
 /* ---- introspection */
 char *fftw_sprint_plan(const fftw_plan p) { return p ? fa_sprint(p) : NULL; }

@@ -52,6 +52,14 @@ typedef struct {
 
 typedef struct { i64 n, is, os; } fa_dim;
 
+/* what FFTW_MEASURE tunes and wisdom remembers */
+typedef struct {
+    size_t chunk_bytes;   /* scratch per chunk */
+    int pipeline;         /* two-stream chunk pipeline on/off */
+    int lmax_multi;       /* longest sub-transform of a multi-pass split */
+    int small_tiles;      /* half-size tiles in the generic LDS kernel */
+} fa_cfg;
+
 typedef struct {
     int buf;
     i64 base;
@@ -71,6 +79,7 @@ typedef struct {
 
 struct fftw_plan_s {
     int type;                   /* FA_C2C / FA_R2C / FA_C2R */
+    fa_cfg cfg;
     int sign;
     unsigned flags;
     int rank;
@@ -143,5 +152,6 @@ int  fa_build(struct fftw_plan_s *p);     /* steps from p->type/dims/hdims; 0 on
 int  fa_device_init(struct fftw_plan_s *p);
 void fa_run(struct fftw_plan_s *p, double *ri, double *ii, double *ro, double *io);
 char *fa_sprint(const struct fftw_plan_s *p);
+fa_cfg fa_default_cfg(void);
 
 #endif

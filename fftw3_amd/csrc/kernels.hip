@@ -175,6 +175,122 @@ pass_generic_kernel(const PassArgs a) {
     }
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* generic LDS pass kernel, in-place form: ONE LDS image (64 KiB for a        */
+/* 4096-element tile) so that two workgroups share a CU.  A stage reads all  */
+/* of an item's butterflies into registers, synchronises, and writes them    */
+/* back to their autosort positions.  Radices with a register butterfly only */
+/* (2,3,4,5,7,8,11,13,16); tiles with a larger prime stage use the ping-pong */
+/* kernel above.                                                             */
+/* ------------------------------------------------------------------------ */
+template <int R>
+FA_DEV void inplace_stage(cplx *A, const cplx *wL, int L, int ld, int Tcur, int Ns, int tid) {
+    constexpr int NB = (4096 / R + 255) / 256;      /* butterflies per item, worst case */
+    const int m = L / R;
+    const int nb = m * Tcur;
+    const int twstep = L / (Ns * R);
+    cplx x[NB][R];
+    int pos[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = u * 256 + tid;
+        pos[u] = -1;
+        if (b < nb) {
+            int j = b / Tcur, t = b - j * Tcur;
+            int k = j % Ns;
+#pragma unroll
+            for (int i = 0; i < R; ++i) x[u][i] = A[(j + i * m) * ld + t];
+            if (Ns > 1) {
+#pragma unroll
+                for (int i = 1; i < R; ++i) x[u][i] = c_mulc(x[u][i], wL[i * k * twstep]);
+            }
+            Bfly<R>::run(x[u]);
+            pos[u] = ((j - k) * R + k) * ld + t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        if (pos[u] >= 0) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) A[pos[u] + q * Ns * ld] = x[u][q];
+        }
+    }
+    __syncthreads();
+}
+
+template <bool VIN, bool VOUT>
+__global__ void __launch_bounds__(256, 2)
+pass_inplace_kernel(const PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fa_lds_raw[];
+    cplx *A = reinterpret_cast<cplx *>(fa_lds_raw);
+    const int tid = threadIdx.x, nth = blockDim.x;
+    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
+    i64 tile = blk % a.ntiles;
+    i64 rest = blk / a.ntiles;
+    i64 soff = 0, doff = 0, twb = 0;
+    for (int d = 1; d < a.ndims; ++d) {
+        i64 idx = rest % a.dn[d];
+        rest /= a.dn[d];
+        soff += idx * a.dis[d];
+        doff += idx * a.dos[d];
+        twb += idx * a.dtw[d];
+    }
+    const int Thi = a.T / a.lo_n;
+    const i64 t0 = tile * Thi;
+    const int Tcur = (int)((a.dn[0] - t0 < Thi) ? (a.dn[0] - t0) : Thi) * a.lo_n;
+    const int L = a.L, ld = a.ld;
+    const int total = L * Tcur;
+    const bool tw_in = a.tw_n && (a.flags & FFTW_AMD_F_TW_IN);
+
+    for (int e = tid; e < total; e += nth) {
+        int l, t;
+        if (a.in_t_fast) { l = e / Tcur; t = e - l * Tcur; }
+        else             { t = e / L;    l = e - t * L; }
+        const int thi = t / a.lo_n, tlo = t - thi * a.lo_n;
+        i64 addr = soff + (i64)l * a.is_l + (t0 + thi) * a.dis[0] + tlo * a.lo_is;
+        cplx v = load_elem<VIN>(a.src, addr, a.src_im, a.flags);
+        if (tw_in) {
+            i64 m = (i64)l * (twb + (t0 + thi) * a.dtw[0]);
+            v = c_mulc(v, tw2(a.tw_lo, a.tw_hi, a.tw_shift, m));
+        }
+        A[l * ld + t] = v;
+    }
+    __syncthreads();
+
+    int Ns = 1;
+    for (int s = 0; s < a.nrad; ++s) {
+        const int r = a.rad[s];
+        switch (r) {
+        case 2:  inplace_stage<2>(A, a.wL, L, ld, Tcur, Ns, tid); break;
+        case 3:  inplace_stage<3>(A, a.wL, L, ld, Tcur, Ns, tid); break;
+        case 4:  inplace_stage<4>(A, a.wL, L, ld, Tcur, Ns, tid); break;
+        case 5:  inplace_stage<5>(A, a.wL, L, ld, Tcur, Ns, tid); break;
+        case 7:  inplace_stage<7>(A, a.wL, L, ld, Tcur, Ns, tid); break;
+        case 8:  inplace_stage<8>(A, a.wL, L, ld, Tcur, Ns, tid); break;
+        case 11: inplace_stage<11>(A, a.wL, L, ld, Tcur, Ns, tid); break;
+        case 13: inplace_stage<13>(A, a.wL, L, ld, Tcur, Ns, tid); break;
+        default: inplace_stage<16>(A, a.wL, L, ld, Tcur, Ns, tid); break;
+        }
+        Ns *= r;
+    }
+
+    for (int e = tid; e < total; e += nth) {
+        int l, t;
+        if (a.out_t_fast) { l = e / Tcur; t = e - l * Tcur; }
+        else              { t = e / L;    l = e - t * L; }
+        cplx v = A[l * ld + t];
+        const int thi = t / a.lo_n, tlo = t - thi * a.lo_n;
+        if (a.tw_n && !tw_in) {
+            i64 m = (i64)l * (twb + (t0 + thi) * a.dtw[0]);
+            v = c_mulc(v, tw2(a.tw_lo, a.tw_hi, a.tw_shift, m));
+        }
+        i64 addr = doff + (i64)l * a.os_l + (t0 + thi) * a.dos[0] + tlo * a.lo_os;
+        store_elem<VOUT>(a.dst, addr, a.dst_im, a.flags, v);
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* strided copy / pad / multiply / permute                                   */
 /* ------------------------------------------------------------------------ */
@@ -783,6 +899,33 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
     }
     if (pa.lo_is % 2) vin = false;
     if (pa.lo_os % 2) vout = false;
+    {
+        /* all radices have register butterflies and the tile is at most 4096
+           elements: the single-image kernel (two workgroups per CU) */
+        static int inplace_mode = -1;
+        bool small_radices = true;
+        if (inplace_mode < 0) { const char *e = getenv("FFTW_AMD_INPLACE"); inplace_mode = e ? atoi(e) : 1; }
+        for (int i = 0; i < d->nradices; ++i)
+            if (d->radices[i] > 16 || d->radices[i] == 6 || d->radices[i] == 9 || d->radices[i] == 10 ||
+                d->radices[i] == 12 || d->radices[i] == 14 || d->radices[i] == 15) small_radices = false;
+        /* ping-pong images that fit twice on a CU need no help; larger tiles take the single image */
+        if (inplace_mode && small_radices && (i64)pa.L * pa.T <= 4096 && lds > 80 * 1024) {
+            static bool done = false;
+            size_t lds1 = (size_t)pa.L * pa.ld * sizeof(cplx);
+            if (!done) {
+                FA_CHECK(hipFuncSetAttribute((const void *)pass_inplace_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                FA_CHECK(hipFuncSetAttribute((const void *)pass_inplace_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                FA_CHECK(hipFuncSetAttribute((const void *)pass_inplace_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                FA_CHECK(hipFuncSetAttribute((const void *)pass_inplace_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                done = true;
+            }
+            if (vin && vout) hipLaunchKernelGGL((pass_inplace_kernel<true, true>), grid, dim3(256), lds1, st, pa);
+            else if (vin) hipLaunchKernelGGL((pass_inplace_kernel<true, false>), grid, dim3(256), lds1, st, pa);
+            else if (vout) hipLaunchKernelGGL((pass_inplace_kernel<false, true>), grid, dim3(256), lds1, st, pa);
+            else hipLaunchKernelGGL((pass_inplace_kernel<false, false>), grid, dim3(256), lds1, st, pa);
+            return 0;
+        }
+    }
     if (vin && vout) launch_pass_variant<true, true>(pa, grid, lds, st);
     else if (vin) launch_pass_variant<true, false>(pa, grid, lds, st);
     else if (vout) launch_pass_variant<false, true>(pa, grid, lds, st);

@@ -256,6 +256,37 @@ def test_layouts_inplace_embed_split_guru_newarray(torch_dev):
     fa.plan_many_dft(1, [n], 0, d1, None, 1, n, o1, None, 1, n, fa.FORWARD).execute()
 
 
+def test_measure_mode_records_wisdom(torch_dev):
+    """FFTW_MEASURE times candidate configurations on the device (it may overwrite the
+    arrays, like the reference), the winner becomes wisdom, and a later
+    FFTW_WISDOM_ONLY plan of the same problem reuses it and computes the same answer"""
+    torch, dev = torch_dev
+    fa.forget_wisdom()
+    n, b = 1 << 16, 64
+    rng = np.random.default_rng(8)
+    x = crand(rng, b, n)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.zeros_like(xd)
+    p = fa.plan_many_dft(1, [n], b, xd, None, 1, n, yd, None, 1, n, fa.FORWARD, fa.MEASURE)
+    text = fa.export_wisdom_to_string()
+    assert "65536:2:2" in text
+    xd.copy_(torch.from_numpy(x))
+    p.execute()
+    torch.cuda.synchronize()
+    ref = oracle_dft(x, (n,), b).reshape(b, n)
+    assert aerror(yd.cpu().numpy(), ref) < TOL
+    fa.forget_wisdom()
+    with pytest.raises(ValueError):
+        fa.plan_many_dft(1, [n], b, xd, None, 1, n, yd, None, 1, n, fa.FORWARD, fa.ESTIMATE | fa.WISDOM_ONLY)
+    assert fa.import_wisdom_from_string(text) == 1
+    p2 = fa.plan_many_dft(1, [n], b, xd, None, 1, n, yd, None, 1, n, fa.FORWARD, fa.ESTIMATE | fa.WISDOM_ONLY)
+    yd.zero_()
+    p2.execute()
+    torch.cuda.synchronize()
+    assert aerror(yd.cpu().numpy(), ref) < TOL
+    fa.forget_wisdom()
+
+
 def test_host_arrays_are_staged(torch_dev):
     """plain host pointers (numpy) take the PCIe staging path, incl. gaps in the output"""
     rng = np.random.default_rng(2)

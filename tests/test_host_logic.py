@@ -218,6 +218,34 @@ def test_api_argument_handling():
     assert abs((a + m + 2 * f) - 5 * 1024 * 10) / (5 * 1024 * 10) < 0.5
 
 
+def test_wisdom_round_trip_and_wisdom_only(tmp_path):
+    """wisdom is text that survives export -> forget -> import; FFTW_WISDOM_ONLY plans
+    only problems it covers; a malformed record leaves the old wisdom intact
+    (reference: transactional import, fftw/fftw_api.c:15577-15581)"""
+    fa.forget_wisdom()
+    x = np.zeros(1 << 14, dtype=complex)
+    y = x.copy()
+    with pytest.raises(ValueError):
+        fa.plan_dft_1d(1 << 14, x, y, fa.FORWARD, fa.ESTIMATE | fa.WISDOM_ONLY)
+    key = "t0 s-1 r1 16384:2:2 h0 i1 o1 p0"
+    rec = "(fftw3_amd_wisdom-1\n  (%s) 268435456 0 512 1 0.125000\n)\n" % key
+    assert fa.import_wisdom_from_string(rec) == 1
+    p = fa.plan_dft_1d(1 << 14, x, y, fa.FORWARD, fa.ESTIMATE | fa.WISDOM_ONLY)
+    assert [d.L for d in p.steps()] == [128, 128]
+    text = fa.export_wisdom_to_string()
+    assert key in text and "268435456 0 512 1" in text
+    assert fa.import_wisdom_from_string("(fftw3_amd_wisdom-1\n  (broken 1 2\n)") == 0
+    assert fa.import_wisdom_from_string("garbage") == 0
+    assert fa.export_wisdom_to_string() == text                # failed imports changed nothing
+    f = str(tmp_path / "wisdom.txt")
+    assert fa.lib.fftw_export_wisdom_to_filename(f.encode()) == 1
+    fa.forget_wisdom()
+    assert key not in fa.export_wisdom_to_string()
+    assert fa.lib.fftw_import_wisdom_from_filename(f.encode()) == 1
+    assert fa.export_wisdom_to_string() == text
+    fa.forget_wisdom()
+
+
 def test_execute_without_device_fails_loudly():
     if fa.device_count() > 0:
         pytest.skip("a HIP device is present")
