@@ -21,7 +21,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_
 
 $(LIBDIR)/libfftw3_amd.so: $(OBJS)
 	mkdir -p $(LIBDIR)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lm
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lm -lpthread
 	ln -sf libfftw3_amd.so $(LIBDIR)/libfftw3.so.3
 	ln -sf libfftw3_amd.so $(LIBDIR)/libfftw3.so
 

@@ -176,6 +176,9 @@ static plan *finish(plan *p, double *ri, double *ii, double *ro, double *io) {
         }
     }
     if (fa_build(p)) { fa_plan_free(p); return NULL; }
+    /* tables and scratch are set up now when a device is present, so that
+       fftw_execute itself allocates nothing (stream capture, latency) */
+    if (fa_hip_device_count() > 0 && p->batch > 0 && fa_device_init(p)) { fa_plan_free(p); return NULL; }
     return p;
 }
 

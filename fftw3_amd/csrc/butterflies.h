@@ -227,4 +227,34 @@ template <> struct Bfly<7> : BflyOdd<7> {};
 template <> struct Bfly<11> : BflyOdd<11> {};
 template <> struct Bfly<13> : BflyOdd<13> {};
 
+
+/* radix 15 = 3 x 5 (input j = i + 3 j2, output k = k2 + 5 k1), constants w15^(i k2) */
+template <> struct Bfly<15> {
+    static FA_DEV void run(cplx *x) {
+        cplx z[3][5];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) z[i][j] = x[i + 3 * j];
+            Bfly<5>::run(z[i]);
+        }
+        const cplx w1 = c_make(0.91354545764260089550, 0.40673664307580020775);
+        const cplx w2 = c_make(0.66913060635885821383, 0.74314482547739423501);
+        const cplx w3 = c_make(0.30901699437494742410, 0.95105651629515357212);
+        const cplx w4 = c_make(-0.10452846326765347140, 0.99452189536827333692);
+        const cplx w6 = c_make(-0.80901699437494742410, 0.58778525229247312917);
+        const cplx w8 = c_make(-0.97814760073380563793, -0.20791169081775933710);
+        z[1][1] = c_mulc(z[1][1], w1); z[1][2] = c_mulc(z[1][2], w2);
+        z[1][3] = c_mulc(z[1][3], w3); z[1][4] = c_mulc(z[1][4], w4);
+        z[2][1] = c_mulc(z[2][1], w2); z[2][2] = c_mulc(z[2][2], w4);
+        z[2][3] = c_mulc(z[2][3], w6); z[2][4] = c_mulc(z[2][4], w8);
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) {
+            cplx c[3] = { z[0][k2], z[1][k2], z[2][k2] };
+            Bfly<3>::run(c);
+            x[k2] = c[0]; x[k2 + 5] = c[1]; x[k2 + 10] = c[2];
+        }
+    }
+};
+
 #endif /* FA_BUTTERFLIES_H */

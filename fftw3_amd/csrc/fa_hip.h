@@ -13,6 +13,8 @@ extern "C" {
 #endif
 
 int   fa_hip_device_count(void);
+/* sequences per tile of the two-stage register kernel for length L, 0 if there is none */
+int   fa_hip_rr_tile(int L);
 void *fa_hip_malloc(size_t nbytes);
 void  fa_hip_free(void *p);
 void *fa_hip_host_malloc(size_t nbytes);  /* pinned; NULL when no device runtime */

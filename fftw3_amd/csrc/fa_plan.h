@@ -5,6 +5,7 @@
 #define FA_PLAN_H
 
 #include <stddef.h>
+#include <pthread.h>
 #include "fftw3.h"
 #include "fftw3_amd.h"
 
@@ -109,6 +110,7 @@ struct fftw_plan_s {
 
     void *stream;
     int dev_ready;
+    pthread_mutex_t lock;       /* fftw_execute is thread-safe in the reference; the plan's scratch is not shareable */
 
     /* chunk pipeline: stage A (steps [0, split)) of chunk c+1 overlaps stage B
        (steps [split, nsteps)) of chunk c on a second stream; each chunk works
@@ -144,6 +146,8 @@ int  fa_lds_able(i64 n);
 i64  fa_next_smooth(i64 n);
 int  fa_radices(i64 L, int *rad);
 int  fa_factor_passes(i64 n, int max_passes, i64 lmax_single, i64 lmax_multi, i64 *lens);
+int  fa_factor_passes_pref(i64 n, int max_passes, i64 lmax_single, i64 lmax_multi, i64 *lens,
+                           int (*tuned)(i64));
 
 /* planner.c */
 struct fftw_plan_s *fa_plan_new(void);

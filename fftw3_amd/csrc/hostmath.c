@@ -220,3 +220,69 @@ int fa_factor_passes(i64 n, int max_passes, i64 lmax_single, i64 lmax_multi, i64
         if (split_rec(n, k, lmax_multi, lens)) return k;
     return 0;
 }
+
+/* ---- splitting with a preference for lengths that have a register kernel ---- */
+
+typedef struct {
+    int k;
+    i64 lmax;
+    int (*tuned)(i64);
+    i64 cur[FA_MAXPASS], best[FA_MAXPASS];
+    int best_bad;
+    double best_ratio;
+    int found;
+} pref_state;
+
+static void pref_rec(pref_state *st, i64 n, int depth, const i64 *divs, int nd) {
+    int i;
+    if (depth == st->k - 1) {
+        int j, bad = 0;
+        i64 mn, mx;
+        if (n > st->lmax) return;
+        st->cur[depth] = n;
+        mn = mx = st->cur[0];
+        for (j = 0; j < st->k; ++j) {
+            if (!st->tuned(st->cur[j])) ++bad;
+            if (st->cur[j] < mn) mn = st->cur[j];
+            if (st->cur[j] > mx) mx = st->cur[j];
+        }
+        if (mn < 2) return;
+        if (!st->found || bad < st->best_bad ||
+            (bad == st->best_bad && (double)mx / (double)mn < st->best_ratio)) {
+            st->found = 1;
+            st->best_bad = bad;
+            st->best_ratio = (double)mx / (double)mn;
+            memcpy(st->best, st->cur, sizeof(st->cur));
+        }
+        return;
+    }
+    for (i = 0; i < nd; ++i) {
+        i64 d = divs[i];
+        if (d < 2) continue;
+        if (d > st->lmax) break;
+        if (n % d) continue;
+        st->cur[depth] = d;
+        pref_rec(st, n / d, depth + 1, divs, nd);
+    }
+}
+
+/* like fa_factor_passes (same number of passes k), but among all splits into k
+   lengths <= lmax_multi pick the one with the fewest lengths that lack a
+   register kernel (`tuned` says which have one), then the most balanced. */
+int fa_factor_passes_pref(i64 n, int max_passes, i64 lmax_single, i64 lmax_multi, i64 *lens,
+                          int (*tuned)(i64)) {
+    int k = fa_factor_passes(n, max_passes, lmax_single, lmax_multi, lens);
+    pref_state st;
+    i64 *divs;
+    int nd;
+    if (k < 2 || !tuned) return k;
+    memset(&st, 0, sizeof(st));
+    st.k = k;
+    st.lmax = lmax_multi;
+    st.tuned = tuned;
+    nd = divisors_of(n, &divs);
+    pref_rec(&st, n, 0, divs, nd);
+    free(divs);
+    if (st.found) memcpy(lens, st.best, sizeof(i64) * (size_t)k);
+    return k;
+}

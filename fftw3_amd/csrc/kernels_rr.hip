@@ -48,8 +48,16 @@ int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *con
     if (d->src_im != 1 || d->dst_im != 1 ||
         (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
         return 1;
-    if (d->L != 64 && d->L != 128 && d->L != 256 && d->L != 512) return 1;
-    T = 8192 / d->L;
+    switch (d->L) {
+    case 64:  T = RRGeom<8, 8>::T; break;
+    case 128: T = RRGeom<16, 8>::T; break;
+    case 256: T = RRGeom<16, 16>::T; break;
+    case 512: T = RRGeom<32, 16>::T; break;
+    case 143: T = RRGeom<11, 13>::T; break;
+    case 105: T = RRGeom<15, 7>::T; break;
+    default: return 1;
+    }
+    if (d->tile != T) return 1;                  /* the planner sized the step for another kernel */
     for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
         pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
         pa.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
@@ -80,6 +88,7 @@ int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *con
         pa.lo_sh = d->tile_lo_n == 2 ? 1 : 2;
         if ((pa.lo_is % 2) || (pa.lo_os % 2)) return 1;
     }
+    if (pa.lo_sh && (T & (T - 1))) return 1;     /* pair tiles need a power-of-two tile */
     T >>= pa.lo_sh;                      /* hi entries per tile */
     pa.ntiles = (pa.dn[0] + T - 1) / T;
     i64 nblocks = pa.ntiles;
@@ -97,6 +106,8 @@ int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *con
     case 128: return dispatch_rr<16, 8>(pa, grid, st, in_t, out_t, tw);
     case 256: return dispatch_rr<16, 16>(pa, grid, st, in_t, out_t, tw);
     case 512: return dispatch_rr<32, 16>(pa, grid, st, in_t, out_t, tw);
+    case 143: return dispatch_rr<11, 13>(pa, grid, st, in_t, out_t, tw);
+    case 105: return dispatch_rr<15, 7>(pa, grid, st, in_t, out_t, tw);
     }
     return 1;
 }
@@ -150,5 +161,18 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
     dim3 grid((unsigned)nblocks, 1, 1);
     if (d->L == 2048) launch_3s<8>(pa, grid, st);
     else launch_3s<16>(pa, grid, st);
+    return 0;
+}
+
+/* tile width the register kernels use for a sub-transform length (0: none) */
+extern "C" int fa_hip_rr_tile(int L) {
+    switch (L) {
+    case 64:  return RRGeom<8, 8>::T;
+    case 128: return RRGeom<16, 8>::T;
+    case 256: return RRGeom<16, 16>::T;
+    case 512: return RRGeom<32, 16>::T;
+    case 143: return RRGeom<11, 13>::T;
+    case 105: return RRGeom<15, 7>::T;
+    }
     return 0;
 }

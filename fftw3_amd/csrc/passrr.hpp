@@ -1,5 +1,6 @@
 /*
- * passrr.hpp -- register-resident two-stage pass for L = R1 * R2 in {64, 128, 256, 512}.
+ * passrr.hpp -- register-resident two-stage pass for L = R1 * R2: the powers of two
+ * 64, 128, 256, 512 and mixed-radix pairs such as 143 = 11 x 13 and 105 = 15 x 7.
  *
  * Same design as pass1024.hpp (which is the R1 = R2 = 32 member of the family,
  * kept separately because it is the measured hot kernel): a workgroup of 256
@@ -23,17 +24,12 @@
 #ifndef FA_PASSRR_HPP
 #define FA_PASSRR_HPP
 
-/* radix-R butterfly with its output permutation */
-template <int R> struct RB;
-template <> struct RB<8> {
-    static FA_DEV void run(cplx *x) { Bfly<8>::run(x); }
+/* radix-R butterfly with its output permutation; bits = ceil(log2 R) */
+constexpr int fa_ceil_log2(int r) { int b = 0; while ((1 << b) < r) ++b; return b; }
+template <int R> struct RB {
+    static FA_DEV void run(cplx *x) { Bfly<R>::run(x); }
     static constexpr int slot(int k) { return k; }
-    static constexpr int bits = 3;
-};
-template <> struct RB<16> {
-    static FA_DEV void run(cplx *x) { Bfly<16>::run(x); }
-    static constexpr int slot(int k) { return k; }
-    static constexpr int bits = 4;
+    static constexpr int bits = fa_ceil_log2(R);
 };
 template <> struct RB<32> {
     static FA_DEV void run(cplx *x) { bfly32(x); }
@@ -51,24 +47,43 @@ template <int R, int BIT, int D, bool HAVE, bool PERM> struct TwTreeR {
 };
 template <int R, int D, bool HAVE, bool PERM> struct TwTreeR<R, -1, D, HAVE, PERM> {
     static FA_DEV void run(cplx *x, const cplx *, cplx acc) {
-        constexpr int S = PERM ? RB<R>::slot(D) : D;
-        if (HAVE) x[S] = c_mulc(x[S], acc);
+        if constexpr (D < R) {                       /* non power-of-two radix: the tree overshoots */
+            constexpr int S = PERM ? RB<R>::slot(D) : D;
+            if (HAVE) x[S] = c_mulc(x[S], acc);
+        }
     }
 };
 
+/* sequences per tile: as many as fit 8192 elements while an item keeps at most
+   ~34 (stage 1) / ~40 (stage 2) elements in registers */
+constexpr int fa_rr_tile(int R1, int R2) {
+    int T = 8192 / (R1 * R2);
+    /* powers of two run with exactly 32 elements per item; the odd-prime butterflies
+       need more temporaries, so their items keep at most 30 / 28 elements (measured:
+       33 / 39 elements spill 150-200 VGPRs) */
+    const bool pow2 = ((R1 & (R1 - 1)) == 0) && ((R2 & (R2 - 1)) == 0);
+    /* the composite radix 15 carries a 3 x 5 scratch array: one butterfly per item */
+    const int lim1 = pow2 ? 32 : (R1 == 15 ? 15 : 30), lim2 = pow2 ? 32 : (R2 == 15 ? 15 : 28);
+    while (T > 1 && ((((R2 * T + 255) / 256) * R1 > lim1) || (((R1 * T + 255) / 256) * R2 > lim2))) --T;
+    return T;
+}
+
 template <int R1, int R2> struct RRGeom {
     static constexpr int L = R1 * R2;
-    static constexpr int T = 8192 / L;
-    static constexpr int Q1 = 32 / R1;
-    static constexpr int Q2 = 32 / R2;
+    static constexpr int T = fa_rr_tile(R1, R2);
+    static constexpr int NB1 = R2 * T;               /* radix-R1 butterflies per tile */
+    static constexpr int NB2 = R1 * T;               /* radix-R2 butterflies per tile */
+    static constexpr int Q1 = (NB1 + 255) / 256;
+    static constexpr int Q2 = (NB2 + 255) / 256;
+    static constexpr int SDTT = R2 * T + (T < 32 ? T : 0);
     /* LDS image of one real plane: element (d, a, t), padded against bank conflicts */
     template <bool IN_T, bool OUT_T> static FA_DEV int idx(int d, int a, int t) {
-        if (IN_T && OUT_T) return d * (R2 * T + (T < 32 ? T : 0)) + a * T + t;
+        if (IN_T && OUT_T) return d * SDTT + a * T + t;
         if (!IN_T && OUT_T) return d * (T * (R2 + 1)) + t * (R2 + 1) + a;
         if (IN_T && !OUT_T) return a * (T * (R1 + 1)) + t * (R1 + 1) + d;
         return t * (R1 * (R2 + 1)) + d * (R2 + 1) + a;
     }
-    static constexpr int lds_doubles = 8192 + (R1 > R2 ? R1 : R2) * T + 64;
+    static constexpr int lds_doubles = L * T + (R1 > R2 ? R1 : R2) * T + R1 * T + 64;
 };
 
 struct PRRTile {
@@ -93,16 +108,18 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
     constexpr int T = G::T, Q1 = G::Q1, Q2 = G::Q2;
     cplx x[Q1][R1];
     int a1[Q1], t1[Q1];
+    bool ok1[Q1];
 
     /* ---- load + stage 1 */
 #pragma unroll
     for (int u = 0; u < Q1; ++u) {
         const int g = u * 256 + tid;
+        ok1[u] = g < G::NB1;                         /* the last butterfly slot may be empty */
         t1[u] = IN_T ? (g % T) : (g / R2);
         a1[u] = IN_T ? (g / T) : (g % R2);
         const double *p = a.src + (i64)a1[u] * a.is_l + FA_TILE_SOFF(a, t1[u]);
         const i64 step = (i64)R2 * a.is_l;
-        if ((t1[u] >> a.lo_sh) < a.Tcur) {
+        if (ok1[u] && (t1[u] >> a.lo_sh) < a.Tcur) {
 #pragma unroll
             for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + i * step);
         } else {
@@ -139,31 +156,37 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
     /* ---- exchange, one real plane at a time */
     cplx y[Q2][R2];
     int d2[Q2], t2[Q2];
+    bool ok2[Q2];
 #pragma unroll
     for (int v = 0; v < Q2; ++v) {
         const int h = v * 256 + tid;
+        ok2[v] = h < G::NB2;
         t2[v] = OUT_T ? (h % T) : (h / R1);
         d2[v] = OUT_T ? (h / T) : (h % R1);
     }
 #pragma unroll
     for (int u = 0; u < Q1; ++u)
+        if (ok1[u]) {
 #pragma unroll
-        for (int d = 0; d < R1; ++d) plane[G::template idx<IN_T, OUT_T>(d, a1[u], t1[u])] = x[u][RB<R1>::slot(d)].x;
+            for (int d = 0; d < R1; ++d) plane[G::template idx<IN_T, OUT_T>(d, a1[u], t1[u])] = x[u][RB<R1>::slot(d)].x;
+        }
     __syncthreads();
 #pragma unroll
     for (int v = 0; v < Q2; ++v)
 #pragma unroll
-        for (int q = 0; q < R2; ++q) y[v][q].x = plane[G::template idx<IN_T, OUT_T>(d2[v], q, t2[v])];
+        for (int q = 0; q < R2; ++q) y[v][q].x = ok2[v] ? plane[G::template idx<IN_T, OUT_T>(d2[v], q, t2[v])] : 0.0;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < Q1; ++u)
+        if (ok1[u]) {
 #pragma unroll
-        for (int d = 0; d < R1; ++d) plane[G::template idx<IN_T, OUT_T>(d, a1[u], t1[u])] = x[u][RB<R1>::slot(d)].y;
+            for (int d = 0; d < R1; ++d) plane[G::template idx<IN_T, OUT_T>(d, a1[u], t1[u])] = x[u][RB<R1>::slot(d)].y;
+        }
     __syncthreads();
 #pragma unroll
     for (int v = 0; v < Q2; ++v)
 #pragma unroll
-        for (int q = 0; q < R2; ++q) y[v][q].y = plane[G::template idx<IN_T, OUT_T>(d2[v], q, t2[v])];
+        for (int q = 0; q < R2; ++q) y[v][q].y = ok2[v] ? plane[G::template idx<IN_T, OUT_T>(d2[v], q, t2[v])] : 0.0;
 
     /* ---- stage 2, output twiddle, store: X[d + R1 c] */
 #pragma unroll
@@ -177,7 +200,7 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
             for (int s = 0; s < RB<R2>::bits; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * R1) << s);
             TwTreeR<R2, RB<R2>::bits - 1, 0, true, true>::run(y[v], pw, base);
         }
-        if ((t2[v] >> a.lo_sh) < a.Tcur) {
+        if (ok2[v] && (t2[v] >> a.lo_sh) < a.Tcur) {
             double *p = a.dst + (i64)d2[v] * a.os_l + FA_TILE_DOFF(a, t2[v]);
             const i64 step = (i64)R1 * a.os_l;
             const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;

@@ -70,6 +70,7 @@ plan *fa_plan_new(void) {
     e = getenv("FFTW_AMD_LMAX_MULTI");
     if (e && atoll(e) >= 16) g_lmax_multi = atoll(e);
     p->cfg = fa_default_cfg();
+    pthread_mutex_init(&p->lock, NULL);
     return p;
 }
 
@@ -111,6 +112,7 @@ void fa_plan_free(plan *p) {
     }
     for (i = 0; i < p->ntabs; ++i) free(p->tabs[i].host);
     free(p->steps);
+    pthread_mutex_destroy(&p->lock);
     free(p);
 }
 
@@ -413,10 +415,10 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
         } else if ((L == 2048 || L == 4096) && is_l == 2 && os_l == 2 && tw_n == 0 && s->tile_lo_n == 1) {
             s->variant = FFTW_AMD_K_R3;     /* three-stage register kernel, whole contiguous rows */
             s->tile = (int)(8192 / L);
-        } else if ((L == 64 || L == 128 || L == 256 || L == 512) &&
-                   s->dim_n[0] * s->tile_lo_n * 4 >= 8192 / L) {
-            s->variant = FFTW_AMD_K_RR;     /* two-stage register kernel, 8192/L sequences per tile */
-            s->tile = (int)(8192 / L);
+        } else if (fa_hip_rr_tile((int)L) > 0 && s->dim_n[0] * s->tile_lo_n * 4 >= fa_hip_rr_tile((int)L) &&
+                   (s->tile_lo_n == 1 || (L & (L - 1)) == 0)) {
+            s->variant = FFTW_AMD_K_RR;     /* two-stage register kernel */
+            s->tile = fa_hip_rr_tile((int)L);
         }
     }
     s->tw_n = tw_n;
@@ -702,6 +704,11 @@ static void emit_rader(plan *p, const fa_axis *ax) {
     buf_release(p, wbuf);
 }
 
+/* lengths with a register kernel (pass1024 / passrr) */
+static int has_register_kernel(i64 L) {
+    return L == 1024 || (L <= 1024 && fa_hip_rr_tile((int)L) > 0);
+}
+
 static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     fa_axis ax = *ax_in;
     i64 lens[FA_MAXPASS];
@@ -732,7 +739,8 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
         if (!rows3s) lmax1 = 1024;
     }
     if (ax.nloops == 0 && !contiguous) lmax1 = FA_LMAX_SINGLE;
-    k = fa_factor_passes(ax.n, FA_MAXPASS, lmax1, contiguous ? p->cfg.lmax_multi : FA_TILE_ELEMS / 8, lens);
+    k = fa_factor_passes_pref(ax.n, FA_MAXPASS, lmax1, contiguous ? p->cfg.lmax_multi : FA_TILE_ELEMS / 8, lens,
+                              getenv("FFTW_AMD_NO_TUNED") ? NULL : has_register_kernel);
     if (k == 0) {
         /* e.g. a prime factor between lmax and FA_PRIME_LDS_MAX cannot happen;
            sizes that do not split fall back to Bluestein */
@@ -1324,7 +1332,17 @@ static double *stage_buf(double **slot, size_t *have, size_t need) {
 static double *g_prof_ms = NULL;
 static long long *g_prof_launches = NULL;
 
+static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *io);
+
+/* serialised per plan: concurrent fftw_execute calls on one plan are legal in the
+   reference (A.c:433, re-entrant executors) but here they share scratch and streams */
 void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
+    pthread_mutex_lock(&p->lock);
+    fa_run_locked(p, ri, ii, ro, io);
+    pthread_mutex_unlock(&p->lock);
+}
+
+static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *io) {
     double *bufs[FA_MAXBUF];
     void *tabs[FA_MAXTAB];
     int i, in_host = 0, out_host = 0;
@@ -1556,9 +1574,17 @@ char *fa_sprint(const plan *p) {
         const fftw_amd_step_desc *d = &p->steps[i];
         len += (size_t)snprintf(s + len, cap - len, "\n  (%s", kind_name(d->kind));
         if (d->kind == FFTW_AMD_STEP_PASS) {
+            /* which kernel runs the pass: reg32x32 / reg2 / reg3 = register-resident
+               (pass1024 / passrr / pass3s), lds = runtime-radix LDS kernel + its radices */
             len += (size_t)snprintf(s + len, cap - len, "-%d/", d->L);
-            for (j = 0; j < d->nradices; ++j)
-                len += (size_t)snprintf(s + len, cap - len, "%s%d", j ? "x" : "", d->radices[j]);
+            if (d->variant == FFTW_AMD_K_P1024) len += (size_t)snprintf(s + len, cap - len, "reg32x32");
+            else if (d->variant == FFTW_AMD_K_RR) len += (size_t)snprintf(s + len, cap - len, "reg2");
+            else if (d->variant == FFTW_AMD_K_R3) len += (size_t)snprintf(s + len, cap - len, "reg3");
+            else {
+                len += (size_t)snprintf(s + len, cap - len, "lds:");
+                for (j = 0; j < d->nradices; ++j)
+                    len += (size_t)snprintf(s + len, cap - len, "%s%d", j ? "x" : "", d->radices[j]);
+            }
             len += (size_t)snprintf(s + len, cap - len, " tile=%d", d->tile);
             if (d->tw_n) len += (size_t)snprintf(s + len, cap - len, " tw=%lld", d->tw_n);
         } else {

@@ -26,6 +26,7 @@ extern "C" int bfly(int r, double *d) {
     case 2: run<2>(d); break; case 3: run<3>(d); break; case 4: run<4>(d); break;
     case 5: run<5>(d); break; case 7: run<7>(d); break; case 8: run<8>(d); break;
     case 11: run<11>(d); break; case 13: run<13>(d); break; case 16: run<16>(d); break;
+    case 15: run<15>(d); break;
     default: return -1;
     }
     return 0;
@@ -43,7 +44,7 @@ def test_butterflies_match_dft():
         lib = C.CDLL(so)
         lib.bfly.argtypes = [C.c_int, C.c_void_p]
         rng = np.random.default_rng(0)
-        for r in (2, 3, 4, 5, 7, 8, 11, 13, 16):
+        for r in (2, 3, 4, 5, 7, 8, 11, 13, 15, 16):
             for _ in range(3):
                 x = rng.random(r) - 0.5 + 1j * (rng.random(r) - 0.5)
                 d = x.copy()
