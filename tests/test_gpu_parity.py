@@ -410,3 +410,79 @@ def test_full_batch_known_answer_cfg2(torch_dev):
     assert worst / 2.0 < TOL
     del xd, yd
     torch.cuda.empty_cache()
+
+
+def test_execute_is_capturable_in_a_hip_graph(torch_dev):
+    """fftw_execute allocates nothing and forks/joins its side streams with events, so a
+    caller can capture it into a HIP graph and replay it (new inputs in the same buffers)"""
+    torch, dev = torch_dev
+    n, b = 1 << 16, 40                    # two passes, several chunks -> the two-stream pipeline is active
+    fa.set_chunk_bytes(8 << 20)
+    try:
+        rng = np.random.default_rng(77)
+        x1, x2 = crand(rng, b, n), crand(rng, b, n)
+        xd = torch.from_numpy(x1).to(dev)
+        yd = torch.zeros_like(xd)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            p = fa.plan_many_dft(1, [n], b, xd, None, 1, n, yd, None, 1, n, fa.FORWARD)
+            p.set_stream(s.cuda_stream)
+            p.execute()                   # warm: everything allocated before the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            p.execute()
+        xd.copy_(torch.from_numpy(x2))
+        yd.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert aerror(yd.cpu().numpy(), oracle_dft(x2, (n,), b).reshape(b, n)) < TOL
+        xd.copy_(torch.from_numpy(x1))
+        g.replay()
+        torch.cuda.synchronize()
+        assert aerror(yd.cpu().numpy(), oracle_dft(x1, (n,), b).reshape(b, n)) < TOL
+    finally:
+        fa.set_chunk_bytes(0)
+
+
+def test_random_composite_shapes_like_check_pl(torch_dev):
+    """the reference's random sweep (fftw/tests/check.pl:186-251): random ranks up to 4,
+    dimensions built from factors <= 13, random vector type (none / contiguous *V /
+    interleaved vV), forward or backward, in or out of place; every case against the oracle"""
+    torch, dev = torch_dev
+    rng = np.random.default_rng(1234)
+    primes = [2, 3, 5, 7, 11, 13]
+    for case in range(60):
+        rank = int(rng.integers(1, 5))
+        shape = []
+        budget = 200000 ** (1.0 / rank)
+        for _ in range(rank):
+            n = 1
+            while True:
+                f = primes[int(rng.integers(0, len(primes)))]
+                if n * f > max(2.0, budget):
+                    break
+                n *= f
+                if rng.random() < 0.25:
+                    break
+            shape.append(n)
+        shape = tuple(shape)
+        nn = int(np.prod(shape))
+        vtype = int(rng.integers(0, 3))
+        v = 1 if vtype == 0 else int(rng.integers(2, 5))
+        sign = -1 if rng.random() < 0.5 else 1
+        inplace = rng.random() < 0.5
+        if vtype == 2:                               # interleaved vectors: stride v, dist 1
+            x = crand(rng, *(shape + (v,)))
+            istride, idist = v, 1
+        else:
+            x = crand(rng, *((v,) + shape))
+            istride, idist = 1, nn
+        xd = torch.from_numpy(x).to(dev)
+        yd = xd if inplace else torch.zeros_like(xd)
+        p = fa.plan_many_dft(rank, list(shape), v, xd, None, istride, idist, yd, None, istride, idist, sign)
+        p.execute()
+        torch.cuda.synchronize()
+        ref = oracle_dft(x, shape, v, sign, istride=istride, idist=idist, ostride=istride, odist=idist)
+        e = aerror(yd.cpu().numpy().reshape(-1), ref)
+        assert e < TOL, (case, shape, v, vtype, sign, inplace, e, p.sprint())

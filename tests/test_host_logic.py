@@ -284,3 +284,40 @@ def test_host_twiddles_match_oracle_bit_for_bit():
             assert fa.cexp(m, n) == (out[0], out[1])
     assert fa.lib.fftw_amd_find_generator(97) == 5 and fa.lib.fftw_amd_find_generator(65537) == 3
     assert fa.lib.fftw_amd_power_mod(3, 65536, 65537) == 1
+
+
+def test_planner_random_composite_shapes():
+    """CPU-tier twin of the GPU random sweep (fftw/tests/check.pl:186-251): the planner's
+    step lists for random shapes / vector types, interpreted with numpy, against the oracle"""
+    r = np.random.default_rng(4321)
+    primes = [2, 3, 5, 7, 11, 13]
+    for case in range(40):
+        rank = int(r.integers(1, 4))
+        shape = []
+        budget = 20000 ** (1.0 / rank)
+        for _ in range(rank):
+            n = 1
+            while True:
+                f = primes[int(r.integers(0, len(primes)))]
+                if n * f > max(2.0, budget):
+                    break
+                n *= f
+                if r.random() < 0.25:
+                    break
+            shape.append(n)
+        shape = tuple(shape)
+        nn = int(np.prod(shape))
+        vtype = int(r.integers(0, 3))
+        v = 1 if vtype == 0 else int(r.integers(2, 5))
+        sign = -1 if r.random() < 0.5 else 1
+        if vtype == 2:
+            x = crand(r, *(shape + (v,)))
+            istride, idist = v, 1
+        else:
+            x = crand(r, *((v,) + shape))
+            istride, idist = 1, nn
+        y = np.zeros_like(x)
+        p = fa.plan_many_dft(rank, list(shape), v, x, None, istride, idist, y, None, istride, idist, sign)
+        run_plan_on_host(p, x, y)
+        ref = oracle_dft(x, shape, v, sign, istride=istride, idist=idist, ostride=istride, odist=idist)
+        assert aerror(y.reshape(-1), ref) < TOL, (case, shape, v, vtype, sign, p.sprint())
