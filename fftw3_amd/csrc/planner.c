@@ -857,24 +857,19 @@ static int axis_pass_count(i64 n) {
    on the half-spectrum array (reference rank_geq2_rdft2 A.c:10111-10282).
    p->dims[].is are strides of the REAL array (doubles), .os of the complex
    array (doubles, so 2 per complex). */
-static void build_r2c(plan *p) {
-    int r = p->rank, a, j;
-    i64 nl = p->dims[r - 1].n, half = nl / 2 + 1;
-    i64 ext[FA_MAXRANK];
-    fa_loc in = { 0, 0, 0 }, out = { 1, 0, p->out_im };
-    fa_axis ax;
-    for (j = 0; j < r; ++j) ext[j] = p->dims[j].n;
-    ext[r - 1] = half;
-
-    memset(&ax, 0, sizeof(ax));
-    if (collect_loops(p, p->dims, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
-
+/* real -> half spectrum along one axis.  ax: the loops (.is = strides in the real
+   source, .os = strides in the complex destination) and the batch loop; rs / cs:
+   element strides of the transform index on the two sides, in doubles. */
+static void emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs, fa_loc out, i64 cs) {
+    fa_axis ax = *axp;
+    i64 half = nl / 2 + 1;
+    int j;
     if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
         (axis_pass_count(nl / 4) < axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
         /* n = 4m: two complex DFTs of size m on (x[4j], x[4j+1]) and (x[4j+2], x[4j+3]),
            then the radix-4 untangle -- the reference's rdft2-ct-dit/4 + hc2cfdft_4 plan,
            chosen when m needs fewer passes than n/2 (n = 2^22: m = 2^20 is 1024 x 1024) */
-        i64 m = nl / 4, zts, lts[FA_MAXLOOPS + 1], total, rs = p->dims[r - 1].is;
+        i64 m = nl / 4, zts, lts[FA_MAXLOOPS + 1], total;
         int zbuf, nd, vloop;
         fa_loc z;
         fa_axis q_ax = ax, lay;
@@ -903,9 +898,9 @@ static void build_r2c(plan *p) {
 
         s = new_step(p, FFTW_AMD_STEP_R2C_POST4);
         s->src_buf = zbuf; s->src_base = 0; s->src_im = 1;
-        s->dst_buf = 1; s->dst_base = 0; s->dst_im = p->out_im;
+        s->dst_buf = out.buf; s->dst_base = out.base; s->dst_im = out.im;
         s->is_l = zts;
-        s->os_l = p->dims[r - 1].os;
+        s->os_l = cs;
         s->aux_n = nl;
         s->aux_valid = lts[vloop];
         tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
@@ -932,19 +927,19 @@ static void build_r2c(plan *p) {
         z.buf = zbuf; z.base = 0; z.im = 1;
 
         half_ax.n = h;
-        half_ax.is = 2 * p->dims[r - 1].is;
+        half_ax.is = 2 * rs;
         half_ax.os = zts;
         half_ax.src = in;
-        half_ax.src.im = p->dims[r - 1].is;     /* odd sample = imaginary part */
+        half_ax.src.im = rs;     /* odd sample = imaginary part */
         half_ax.dst = z;
         for (j = 0; j < ax.nloops; ++j) half_ax.loops[j].os = lts[j];
         fa_emit_axis(p, &half_ax);
 
         s = new_step(p, FFTW_AMD_STEP_R2C_POST);
         s->src_buf = zbuf; s->src_base = 0; s->src_im = 1;
-        s->dst_buf = 1; s->dst_base = 0; s->dst_im = p->out_im;
+        s->dst_buf = out.buf; s->dst_base = out.base; s->dst_im = out.im;
         s->is_l = zts;
-        s->os_l = p->dims[r - 1].os;
+        s->os_l = cs;
         s->aux_n = nl;
         tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
         nd = 0;
@@ -968,7 +963,7 @@ static void build_r2c(plan *p) {
         fbuf = buf_acquire(p, total);
         f.buf = fbuf; f.base = 0; f.im = 1;
         full_ax.n = nl;
-        full_ax.is = p->dims[r - 1].is;
+        full_ax.is = rs;
         full_ax.os = fts;
         full_ax.src = in;
         full_ax.dst = f;
@@ -980,9 +975,25 @@ static void build_r2c(plan *p) {
             d[nd].n = ax.loops[j].n; d[nd].is = lts[j]; d[nd].os = ax.loops[j].os;
             d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
         }
-        emit_copy(p, FFTW_AMD_STEP_COPY, f, out, half, half, fts, p->dims[r - 1].os, d, nd, 0, -1, -1);
+        emit_copy(p, FFTW_AMD_STEP_COPY, f, out, half, half, fts, cs, d, nd, 0, -1, -1);
         buf_release(p, fbuf);
     }
+
+}
+
+static void build_r2c(plan *p) {
+    int r = p->rank, a, j;
+    i64 nl = p->dims[r - 1].n, half = nl / 2 + 1;
+    i64 ext[FA_MAXRANK];
+    fa_loc in = { 0, 0, 0 }, out = { 1, 0, p->out_im };
+    fa_axis ax;
+    for (j = 0; j < r; ++j) ext[j] = p->dims[j].n;
+    ext[r - 1] = half;
+
+    memset(&ax, 0, sizeof(ax));
+    if (collect_loops(p, p->dims, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
+
+    emit_r2c_axis(p, nl, &ax, in, p->dims[r - 1].is, out, p->dims[r - 1].os);
 
     for (a = r - 2; a >= 0; --a) {
         fa_axis cx;
@@ -998,6 +1009,132 @@ static void build_r2c(plan *p) {
 /* c2r: complex backward DFTs over the leading dims (into scratch, so the
    caller's input survives), then half spectrum -> real along the last dim.
    p->dims[].is: strides of the complex array, .os: of the real array. */
+/* half spectrum -> real along one axis (unnormalised backward).  ax: the loops
+   (.is = strides in the complex source `cur`, .os = strides in the real
+   destination); cs / rs: element strides of the transform index, in doubles. */
+static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 cs, fa_loc out, i64 rs) {
+    fa_axis ax = *axp;
+    int j;
+    if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
+        (axis_pass_count(nl / 4) < axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
+        /* transpose of the radix-4 r2c plan: tangle into two quarter-length
+           spectra, two backward complex DFTs of size m straight into the real array */
+        i64 m = nl / 4, zts, lts[FA_MAXLOOPS + 1], total;
+        int zbuf, nd, vloop;
+        fa_loc z;
+        fa_axis q_ax = ax, lay;
+        sdim d[FA_MAXLOOPS + 1];
+        fftw_amd_step_desc *s;
+        vloop = q_ax.nloops++;
+        q_ax.loops[vloop].n = 2;
+        q_ax.loops[vloop].is = 0;
+        q_ax.loops[vloop].os = 2 * rs;
+        lay = q_ax;
+        lay.is = 2;
+        lay.loops[vloop].is = 1;
+        total = scratch_layout(&lay, m, &zts, lts);
+        zbuf = buf_acquire(p, total);
+        z.buf = zbuf; z.base = 0; z.im = 1;
+        q_ax.dense = (rs == 1);
+
+        s = new_step(p, FFTW_AMD_STEP_C2R_PRE4);
+        s->src_buf = cur.buf; s->src_base = cur.base; s->src_im = cur.im;
+        s->dst_buf = zbuf; s->dst_base = 0; s->dst_im = 1;
+        s->is_l = cs;
+        s->os_l = zts;
+        s->aux_n = nl;
+        s->aux_valid = lts[vloop];
+        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        nd = 0;
+        for (j = 0; j < ax.nloops; ++j) {
+            d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
+            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+        }
+        step_set_dims(p, s, d, nd, -1);
+
+        q_ax.n = m;
+        q_ax.is = zts;
+        q_ax.os = 4 * rs;
+        q_ax.src = z;
+        q_ax.dst = out;
+        q_ax.dst.im = rs;
+        q_ax.flags_in = FFTW_AMD_F_SWAP_IN;
+        q_ax.flags_out = FFTW_AMD_F_SWAP_OUT;
+        for (j = 0; j < q_ax.nloops; ++j) q_ax.loops[j].is = lts[j];
+        fa_emit_axis(p, &q_ax);
+        buf_release(p, zbuf);
+    } else if (nl % 2 == 0 && nl >= 2) {
+        i64 h = nl / 2, zts, lts[FA_MAXLOOPS], total;
+        int zbuf, nd;
+        fa_loc z;
+        fa_axis half_ax, lay;
+        sdim d[FA_MAXLOOPS];
+        fftw_amd_step_desc *s;
+        lay = ax;
+        lay.is = 1;
+        total = scratch_layout(&lay, h, &zts, lts);
+        zbuf = buf_acquire(p, total);
+        z.buf = zbuf; z.base = 0; z.im = 1;
+
+        s = new_step(p, FFTW_AMD_STEP_C2R_PRE);
+        s->src_buf = cur.buf; s->src_base = cur.base; s->src_im = cur.im;
+        s->dst_buf = zbuf; s->dst_base = 0; s->dst_im = 1;
+        s->is_l = cs;
+        s->os_l = zts;
+        s->aux_n = nl;
+        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        nd = 0;
+        for (j = 0; j < ax.nloops; ++j) {
+            d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
+            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+        }
+        step_set_dims(p, s, d, nd, -1);
+
+        half_ax = ax;
+        half_ax.n = h;
+        half_ax.is = zts;
+        half_ax.os = 2 * rs;
+        half_ax.src = z;
+        half_ax.dst = out;
+        half_ax.dst.im = rs;
+        half_ax.flags_in = FFTW_AMD_F_SWAP_IN;
+        half_ax.flags_out = FFTW_AMD_F_SWAP_OUT;
+        for (j = 0; j < ax.nloops; ++j) half_ax.loops[j].is = lts[j];
+        fa_emit_axis(p, &half_ax);
+        buf_release(p, zbuf);
+    } else {
+        i64 fts, lts[FA_MAXLOOPS], total;
+        int fbuf, nd;
+        fa_loc f;
+        fa_axis full_ax, lay;
+        sdim d[FA_MAXLOOPS];
+        lay = ax;
+        lay.is = 1;
+        total = scratch_layout(&lay, nl, &fts, lts);
+        fbuf = buf_acquire(p, total);
+        f.buf = fbuf; f.base = 0; f.im = 1;
+        nd = 0;
+        for (j = 0; j < ax.nloops; ++j) {
+            d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
+            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+        }
+        emit_copy(p, FFTW_AMD_STEP_HERM_EXPAND, cur, f, nl, nl, cs, fts, d, nd, 0, -1, -1);
+        full_ax = ax;
+        full_ax.n = nl;
+        full_ax.is = fts;
+        full_ax.os = rs;
+        full_ax.src = f;
+        full_ax.dst = out;
+        full_ax.flags_in = FFTW_AMD_F_SWAP_IN;
+        /* backward by the swap identity: the real result is the imaginary
+           slot of the swapped output, so swap on store and keep the real part */
+        full_ax.flags_out = FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_REAL_OUT;
+        for (j = 0; j < ax.nloops; ++j) full_ax.loops[j].is = lts[j];
+        fa_emit_axis(p, &full_ax);
+        buf_release(p, fbuf);
+    }
+}
+
 static void build_c2r(plan *p) {
     int r = p->rank, a, j;
     i64 nl = p->dims[r - 1].n, half = nl / 2 + 1;
@@ -1066,124 +1203,7 @@ static void build_c2r(plan *p) {
         if (collect_loops(&view, td, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
     }
 
-    if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
-        (axis_pass_count(nl / 4) < axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
-        /* transpose of the radix-4 r2c plan: tangle into two quarter-length
-           spectra, two backward complex DFTs of size m straight into the real array */
-        i64 m = nl / 4, zts, lts[FA_MAXLOOPS + 1], total, rs = p->dims[r - 1].os;
-        int zbuf, nd, vloop;
-        fa_loc z;
-        fa_axis q_ax = ax, lay;
-        sdim d[FA_MAXLOOPS + 1];
-        fftw_amd_step_desc *s;
-        vloop = q_ax.nloops++;
-        q_ax.loops[vloop].n = 2;
-        q_ax.loops[vloop].is = 0;
-        q_ax.loops[vloop].os = 2 * rs;
-        lay = q_ax;
-        lay.is = 2;
-        lay.loops[vloop].is = 1;
-        total = scratch_layout(&lay, m, &zts, lts);
-        zbuf = buf_acquire(p, total);
-        z.buf = zbuf; z.base = 0; z.im = 1;
-        q_ax.dense = (rs == 1);
-
-        s = new_step(p, FFTW_AMD_STEP_C2R_PRE4);
-        s->src_buf = cur.buf; s->src_base = cur.base; s->src_im = cur.im;
-        s->dst_buf = zbuf; s->dst_base = 0; s->dst_im = 1;
-        s->is_l = cdims[r - 1].is;
-        s->os_l = zts;
-        s->aux_n = nl;
-        s->aux_valid = lts[vloop];
-        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
-        nd = 0;
-        for (j = 0; j < ax.nloops; ++j) {
-            d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
-            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
-        }
-        step_set_dims(p, s, d, nd, -1);
-
-        q_ax.n = m;
-        q_ax.is = zts;
-        q_ax.os = 4 * rs;
-        q_ax.src = z;
-        q_ax.dst = out;
-        q_ax.dst.im = rs;
-        q_ax.flags_in = FFTW_AMD_F_SWAP_IN;
-        q_ax.flags_out = FFTW_AMD_F_SWAP_OUT;
-        for (j = 0; j < q_ax.nloops; ++j) q_ax.loops[j].is = lts[j];
-        fa_emit_axis(p, &q_ax);
-        buf_release(p, zbuf);
-    } else if (nl % 2 == 0 && nl >= 2) {
-        i64 h = nl / 2, zts, lts[FA_MAXLOOPS], total;
-        int zbuf, nd;
-        fa_loc z;
-        fa_axis half_ax, lay;
-        sdim d[FA_MAXLOOPS];
-        fftw_amd_step_desc *s;
-        lay = ax;
-        lay.is = 1;
-        total = scratch_layout(&lay, h, &zts, lts);
-        zbuf = buf_acquire(p, total);
-        z.buf = zbuf; z.base = 0; z.im = 1;
-
-        s = new_step(p, FFTW_AMD_STEP_C2R_PRE);
-        s->src_buf = cur.buf; s->src_base = cur.base; s->src_im = cur.im;
-        s->dst_buf = zbuf; s->dst_base = 0; s->dst_im = 1;
-        s->is_l = cdims[r - 1].is;
-        s->os_l = zts;
-        s->aux_n = nl;
-        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
-        nd = 0;
-        for (j = 0; j < ax.nloops; ++j) {
-            d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
-            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
-        }
-        step_set_dims(p, s, d, nd, -1);
-
-        half_ax = ax;
-        half_ax.n = h;
-        half_ax.is = zts;
-        half_ax.os = 2 * p->dims[r - 1].os;
-        half_ax.src = z;
-        half_ax.dst = out;
-        half_ax.dst.im = p->dims[r - 1].os;
-        half_ax.flags_in = FFTW_AMD_F_SWAP_IN;
-        half_ax.flags_out = FFTW_AMD_F_SWAP_OUT;
-        for (j = 0; j < ax.nloops; ++j) half_ax.loops[j].is = lts[j];
-        fa_emit_axis(p, &half_ax);
-        buf_release(p, zbuf);
-    } else {
-        i64 fts, lts[FA_MAXLOOPS], total;
-        int fbuf, nd;
-        fa_loc f;
-        fa_axis full_ax, lay;
-        sdim d[FA_MAXLOOPS];
-        lay = ax;
-        lay.is = 1;
-        total = scratch_layout(&lay, nl, &fts, lts);
-        fbuf = buf_acquire(p, total);
-        f.buf = fbuf; f.base = 0; f.im = 1;
-        nd = 0;
-        for (j = 0; j < ax.nloops; ++j) {
-            d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
-            d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
-        }
-        emit_copy(p, FFTW_AMD_STEP_HERM_EXPAND, cur, f, nl, nl, cdims[r - 1].is, fts, d, nd, 0, -1, -1);
-        full_ax = ax;
-        full_ax.n = nl;
-        full_ax.is = fts;
-        full_ax.os = p->dims[r - 1].os;
-        full_ax.src = f;
-        full_ax.dst = out;
-        full_ax.flags_in = FFTW_AMD_F_SWAP_IN;
-        /* backward by the swap identity: the real result is the imaginary
-           slot of the swapped output, so swap on store and keep the real part */
-        full_ax.flags_out = FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_REAL_OUT;
-        for (j = 0; j < ax.nloops; ++j) full_ax.loops[j].is = lts[j];
-        fa_emit_axis(p, &full_ax);
-        buf_release(p, fbuf);
-    }
+    emit_c2r_axis(p, nl, &ax, cur, cdims[r - 1].is, out, p->dims[r - 1].os);
     if (cbuf >= 0) buf_release(p, cbuf);
 }
 
