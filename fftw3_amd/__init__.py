@@ -44,6 +44,14 @@ MAX_RADICES = 16
 
 STEP_PASS, STEP_COPY, STEP_R2C_POST, STEP_C2R_PRE, STEP_RADER_MUL, STEP_HERM_EXPAND = 1, 2, 3, 4, 5, 6
 STEP_R2C_POST4, STEP_C2R_PRE4 = 7, 8
+STEP_R2R = 9
+# fftw_r2r_kind (include/fftw3.h)
+R2HC, HC2R, DHT, REDFT00, REDFT01, REDFT10, REDFT11, RODFT00, RODFT01, RODFT10, RODFT11 = range(11)
+# FFTW_AMD_R2R_* step modes (include/fftw3_amd.h)
+(R2R_PRE_HC2R, R2R_PRE_E10, R2R_PRE_O10, R2R_PRE_E01, R2R_PRE_O01, R2R_PRE_E00, R2R_PRE_O00,
+ R2R_PRE_E11, R2R_PRE_O11, R2R_PRE_E11ODD, R2R_PRE_O11ODD, R2R_POST_R2HC, R2R_POST_DHT,
+ R2R_POST_E10, R2R_POST_O10, R2R_POST_E01, R2R_POST_O01, R2R_POST_E00, R2R_POST_O00,
+ R2R_POST_E11, R2R_POST_O11, R2R_POST_E11ODD, R2R_POST_O11ODD) = range(1, 24)
 F_SWAP_IN, F_SWAP_OUT, F_REAL_IN, F_REAL_OUT = 1, 2, 4, 8
 F_MUL_TABLE, F_MUL_CONJ, F_PERM_SRC, F_PERM_DST, F_CONJ_OUT, F_TW_IN = 16, 32, 64, 128, 256, 512
 
@@ -117,6 +125,15 @@ _sig("fftw_plan_guru64_dft_r2c", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.PO
      _vp, _vp, C.c_uint)
 _sig("fftw_plan_guru64_dft_c2r", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.POINTER(iodim64),
      _vp, _vp, C.c_uint)
+_sig("fftw_execute_r2r", None, _vp, _vp, _vp)
+_sig("fftw_plan_r2r", _vp, C.c_int, _ip, _vp, _vp, _ip, C.c_uint)
+_sig("fftw_plan_r2r_1d", _vp, C.c_int, _vp, _vp, C.c_int, C.c_uint)
+_sig("fftw_plan_r2r_2d", _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_uint)
+_sig("fftw_plan_r2r_3d", _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint)
+_sig("fftw_plan_many_r2r", _vp, C.c_int, _ip, C.c_int, _vp, _ip, C.c_int, C.c_int,
+     _vp, _ip, C.c_int, C.c_int, _ip, C.c_uint)
+_sig("fftw_plan_guru64_r2r", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.POINTER(iodim64),
+     _vp, _vp, _ip, C.c_uint)
 _sig("fftw_destroy_plan", None, _vp)
 _sig("fftw_cleanup", None)
 _sig("fftw_forget_wisdom", None)
@@ -219,6 +236,10 @@ class Plan(object):
     def execute_dft_c2r(self, i, o):
         self._need_device()
         lib.fftw_execute_dft_c2r(self.handle, ptr(i), ptr(o))
+
+    def execute_r2r(self, i, o):
+        self._need_device()
+        lib.fftw_execute_r2r(self.handle, ptr(i), ptr(o))
 
     def sync(self):
         lib.fftw_amd_plan_sync(self.handle)
@@ -357,6 +378,36 @@ def plan_dft_r2c_3d(n0, n1, n2, i, o, flags=ESTIMATE):
 
 def plan_dft_c2r_3d(n0, n1, n2, i, o, flags=ESTIMATE):
     return Plan(lib.fftw_plan_dft_c2r_3d(n0, n1, n2, ptr(i), ptr(o), flags), (i, o))
+
+
+def plan_r2r(rank, n, i, o, kind, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_r2r(rank, _ints(n), ptr(i), ptr(o), _ints(kind), flags), (i, o))
+
+
+def plan_r2r_1d(n, i, o, kind, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_r2r_1d(n, ptr(i), ptr(o), kind, flags), (i, o))
+
+
+def plan_r2r_2d(n0, n1, i, o, kind0, kind1, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_r2r_2d(n0, n1, ptr(i), ptr(o), kind0, kind1, flags), (i, o))
+
+
+def plan_r2r_3d(n0, n1, n2, i, o, kind0, kind1, kind2, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_r2r_3d(n0, n1, n2, ptr(i), ptr(o), kind0, kind1, kind2, flags), (i, o))
+
+
+def plan_many_r2r(rank, n, howmany, i, inembed, istride, idist, o, onembed, ostride, odist,
+                  kind, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_many_r2r(rank, _ints(n), howmany, ptr(i), _ints(inembed), istride,
+                                       idist, ptr(o), _ints(onembed), ostride, odist, _ints(kind),
+                                       flags), (i, o))
+
+
+def plan_guru64_r2r(dims, howmany_dims, i, o, kind, flags=ESTIMATE):
+    """dims / howmany_dims: sequences of (n, is, os) in doubles; kind: one fftw_r2r_kind per dim."""
+    return Plan(lib.fftw_plan_guru64_r2r(len(dims), _iodims(dims), len(howmany_dims),
+                                         _iodims(howmany_dims), ptr(i), ptr(o), _ints(kind), flags),
+                (i, o))
 
 
 def _iodims(dims):

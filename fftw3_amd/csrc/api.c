@@ -42,6 +42,10 @@ static void wis_key(const plan *p, char *key, size_t cap) {
     len += (size_t)snprintf(key + len, cap - len, "t%d s%d r%d", p->type, p->sign, p->rank);
     for (i = 0; i < p->rank && len < cap; ++i)
         len += (size_t)snprintf(key + len, cap - len, " %lld:%lld:%lld", p->dims[i].n, p->dims[i].is, p->dims[i].os);
+    if (p->type == FA_R2R) {
+        len += (size_t)snprintf(key + len, cap - len, " k");
+        for (i = 0; i < p->rank && len < cap; ++i) len += (size_t)snprintf(key + len, cap - len, "%d.", p->kinds[i]);
+    }
     len += (size_t)snprintf(key + len, cap - len, " h%d", p->hrank);
     for (i = 0; i < p->hrank && len < cap; ++i)
         len += (size_t)snprintf(key + len, cap - len, " %lld:%lld:%lld", p->hdims[i].n, p->hdims[i].is, p->hdims[i].os);
@@ -80,7 +84,7 @@ static plan *clone_problem(const plan *p, fa_cfg c) {
     if (!q) return NULL;
     q->type = p->type; q->sign = p->sign; q->flags = p->flags;
     q->rank = p->rank; q->hrank = p->hrank;
-    for (i = 0; i < p->rank; ++i) q->dims[i] = p->dims[i];
+    for (i = 0; i < p->rank; ++i) { q->dims[i] = p->dims[i]; q->kinds[i] = p->kinds[i]; }
     for (i = 0; i < p->hrank; ++i) q->hdims[i] = p->hdims[i];
     q->in_im = p->in_im; q->out_im = p->out_im;
     q->single_chunk = p->single_chunk;
@@ -128,7 +132,7 @@ static plan *finish(plan *p, double *ri, double *ii, double *ro, double *io) {
         cnt *= e;
     }
     for (i = 0; i < p->hrank; ++i) cnt *= p->hdims[i].n;
-    p->out_written = (p->type == FA_C2R) ? cnt : 2 * cnt;
+    p->out_written = FA_REAL_OUT(p->type) ? cnt : 2 * cnt;
     {
         char key[320];
         wis_entry *w;
@@ -503,51 +507,98 @@ fftw_plan fftw_plan_guru_split_dft_c2r(int rank, const fftw_iodim *dims, int how
     GURU32(fftw_plan_guru64_split_dft_c2r, ri, ii, out, flags);
 }
 
-/* ---- r2r: outside the hot path; symbols kept so callers link */
-fftw_plan fftw_plan_many_r2r(int rank, const int *n, int howmany, double *in, const int *inembed,
-                             int istride, int idist, double *out, const int *onembed, int ostride,
-                             int odist, const fftw_r2r_kind *kind, unsigned flags) {
-    (void)rank; (void)n; (void)howmany; (void)in; (void)inembed; (void)istride; (void)idist;
-    (void)out; (void)onembed; (void)ostride; (void)odist; (void)kind; (void)flags;
-    return NULL;
+/* ---- r2r (reference fftw/fftw_api.c:738-840, 1235-1257, 1409-1430): every
+   dim carries its own kind; strides are in doubles on both sides */
+static plan *mk_r2r(int rank, const fftw_iodim64 *dims, int hrank, const fftw_iodim64 *hdims,
+                    double *in, double *out, const fftw_r2r_kind *kind, unsigned flags) {
+    plan *p;
+    int i, k = 0, same = 1;
+    if (!dims_ok(rank, dims) || !hdims_ok(hrank, hdims)) return NULL;
+    if (rank > 0 && !kind) return NULL;
+    for (i = 0; i < rank; ++i) {
+        if ((int)kind[i] < FFTW_R2HC || (int)kind[i] > FFTW_RODFT11) return NULL;
+        /* REDFT00 of one point has logical size 0: no solver applies in the reference either
+           (redft00e applicable: n > 1, fftw/fftw_api.c:11842-11850) */
+        if (kind[i] == FFTW_REDFT00 && dims[i].n < 2) return NULL;
+    }
+    p = fa_plan_new();
+    if (!p) return NULL;
+    p->type = FA_R2R;
+    p->sign = FFTW_FORWARD;
+    p->flags = flags;
+    p->rank = rank;
+    for (i = 0; i < rank; ++i) {
+        p->dims[i].n = dims[i].n;
+        p->dims[i].is = dims[i].is;
+        p->dims[i].os = dims[i].os;
+        p->kinds[i] = (int)kind[i];
+        if (dims[i].is != dims[i].os) same = 0;
+    }
+    for (i = 0; i < hrank; ++i) {
+        if (hdims[i].n == 1) continue;
+        p->hdims[k].n = hdims[i].n;
+        p->hdims[k].is = hdims[i].is;
+        p->hdims[k].os = hdims[i].os;
+        if (hdims[i].is != hdims[i].os) same = 0;
+        ++k;
+    }
+    p->hrank = k;
+    pick_batch(p);
+    p->in_im = p->out_im = 0;
+    /* in place with different layouts: one chunk, so that the first axis has read
+       everything into scratch before anything is written back */
+    if (in == out && !same) p->single_chunk = 1;
+    return finish(p, in, in, out, out);
 }
-fftw_plan fftw_plan_r2r(int rank, const int *n, double *in, double *out,
-                        const fftw_r2r_kind *kind, unsigned flags) {
-    (void)rank; (void)n; (void)in; (void)out; (void)kind; (void)flags;
-    return NULL;
-}
-fftw_plan fftw_plan_r2r_1d(int n, double *in, double *out, fftw_r2r_kind kind, unsigned flags) {
-    (void)n; (void)in; (void)out; (void)kind; (void)flags;
-    return NULL;
-}
-fftw_plan fftw_plan_r2r_2d(int n0, int n1, double *in, double *out, fftw_r2r_kind k0,
-                           fftw_r2r_kind k1, unsigned flags) {
-    (void)n0; (void)n1; (void)in; (void)out; (void)k0; (void)k1; (void)flags;
-    return NULL;
-}
-fftw_plan fftw_plan_r2r_3d(int n0, int n1, int n2, double *in, double *out, fftw_r2r_kind k0,
-                           fftw_r2r_kind k1, fftw_r2r_kind k2, unsigned flags) {
-    (void)n0; (void)n1; (void)n2; (void)in; (void)out; (void)k0; (void)k1; (void)k2; (void)flags;
-    return NULL;
+
+fftw_plan fftw_plan_guru64_r2r(int rank, const fftw_iodim64 *dims, int howmany_rank,
+                               const fftw_iodim64 *howmany_dims, double *in, double *out,
+                               const fftw_r2r_kind *kind, unsigned flags) {
+    return mk_r2r(rank, dims, howmany_rank, howmany_dims, in, out, kind, flags);
 }
 fftw_plan fftw_plan_guru_r2r(int rank, const fftw_iodim *dims, int howmany_rank,
                              const fftw_iodim *howmany_dims, double *in, double *out,
                              const fftw_r2r_kind *kind, unsigned flags) {
-    (void)rank; (void)dims; (void)howmany_rank; (void)howmany_dims; (void)in; (void)out;
-    (void)kind; (void)flags;
-    return NULL;
+    fftw_iodim64 d[FA_MAXRANK], h[FA_MAXRANK];
+    if (rank < 0 || rank > FA_MAXRANK || howmany_rank < 0 || howmany_rank > FA_MAXRANK) return NULL;
+    to64(rank, dims, d);
+    to64(howmany_rank, howmany_dims, h);
+    return mk_r2r(rank, d, howmany_rank, h, in, out, kind, flags);
 }
-fftw_plan fftw_plan_guru64_r2r(int rank, const fftw_iodim64 *dims, int howmany_rank,
-                               const fftw_iodim64 *howmany_dims, double *in, double *out,
-                               const fftw_r2r_kind *kind, unsigned flags) {
-    (void)rank; (void)dims; (void)howmany_rank; (void)howmany_dims; (void)in; (void)out;
-    (void)kind; (void)flags;
-    return NULL;
+fftw_plan fftw_plan_many_r2r(int rank, const int *n, int howmany, double *in, const int *inembed,
+                             int istride, int idist, double *out, const int *onembed, int ostride,
+                             int odist, const fftw_r2r_kind *kind, unsigned flags) {
+    fftw_iodim64 d[FA_MAXRANK], h;
+    if (!many_ok(rank, n, howmany)) return NULL;
+    rowmajor(rank, n, inembed ? inembed : n, onembed ? onembed : n, istride, ostride, d);
+    h.n = howmany; h.is = idist; h.os = odist;
+    return mk_r2r(rank, d, 1, &h, in, out, kind, flags);
+}
+fftw_plan fftw_plan_r2r(int rank, const int *n, double *in, double *out,
+                        const fftw_r2r_kind *kind, unsigned flags) {
+    return fftw_plan_many_r2r(rank, n, 1, in, NULL, 1, 1, out, NULL, 1, 1, kind, flags);
+}
+fftw_plan fftw_plan_r2r_1d(int n, double *in, double *out, fftw_r2r_kind kind, unsigned flags) {
+    return fftw_plan_r2r(1, &n, in, out, &kind, flags);
+}
+fftw_plan fftw_plan_r2r_2d(int n0, int n1, double *in, double *out, fftw_r2r_kind k0,
+                           fftw_r2r_kind k1, unsigned flags) {
+    int n[2];
+    fftw_r2r_kind k[2];
+    n[0] = n0; n[1] = n1;
+    k[0] = k0; k[1] = k1;
+    return fftw_plan_r2r(2, n, in, out, k, flags);
+}
+fftw_plan fftw_plan_r2r_3d(int n0, int n1, int n2, double *in, double *out, fftw_r2r_kind k0,
+                           fftw_r2r_kind k1, fftw_r2r_kind k2, unsigned flags) {
+    int n[3];
+    fftw_r2r_kind k[3];
+    n[0] = n0; n[1] = n1; n[2] = n2;
+    k[0] = k0; k[1] = k1; k[2] = k2;
+    return fftw_plan_r2r(3, n, in, out, k, flags);
 }
 void fftw_execute_r2r(const fftw_plan p, double *in, double *out) {
-    (void)p; (void)in; (void)out;
-    fprintf(stderr, "fftw3_amd: r2r transforms are not implemented\n");
-    abort();
+    fa_run(p, in, in, out, out);
 }
 
 /* ------------------------------------------------------------ execution */

@@ -28,7 +28,9 @@ typedef long long i64;
 /* complex elements per LDS image: 160 KiB / (2 images * 16 B) */
 #define FA_LDS_ELEMS 5120
 
-enum { FA_C2C = 0, FA_R2C = 1, FA_C2R = 2 };
+enum { FA_C2C = 0, FA_R2C = 1, FA_C2R = 2, FA_R2R = 3 };
+#define FA_REAL_IN(t)  ((t) == FA_R2C || (t) == FA_R2R)
+#define FA_REAL_OUT(t) ((t) == FA_C2R || (t) == FA_R2R)
 
 enum {
     FA_TAB_STAGE = 1,   /* (cos,sin)(2 pi m / n), m in [0,n) */
@@ -79,7 +81,8 @@ typedef struct {
 } fa_axis;
 
 struct fftw_plan_s {
-    int type;                   /* FA_C2C / FA_R2C / FA_C2R */
+    int type;                   /* FA_C2C / FA_R2C / FA_C2R / FA_R2R */
+    int kinds[FA_MAXRANK];      /* FA_R2R: fftw_r2r_kind of every dim */
     fa_cfg cfg;
     int sign;
     unsigned flags;

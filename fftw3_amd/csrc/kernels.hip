@@ -420,6 +420,176 @@ __global__ void __launch_bounds__(256) c2r_pre_kernel(const RealArgs a) {
 
 
 /* ------------------------------------------------------------------------ */
+/* r2r pre / post processing                                                 */
+/* ------------------------------------------------------------------------ */
+/* One work item per index k of one transform; the flattened index runs over
+   the loops in order of the user-side stride with k inserted at position kpos,
+   so neighbouring work items touch neighbouring user elements whichever axis is
+   transformed.  tw(m) = exp(+2 pi i m / M), M = 4n (kinds 01/10) or 8n (11).
+   Index maps and their derivations: DESIGN.md section 9; the reference's loops
+   with the same roles are cited at emit_r2r_axis in planner.c. */
+struct R2RArgs {
+    const double *src;
+    double *dst;
+    i64 src_im, dst_im;
+    i64 is_k, os_k;
+    i64 n, K, total;
+    i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    int tw_shift;
+    int ndims, kpos, mode;
+};
+
+__global__ void __launch_bounds__(256) r2r_kernel(const R2RArgs a) {
+    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 n = a.n;
+    for (; gid < a.total; gid += stride) {
+        i64 rest = gid, k = 0, soff = 0, doff = 0;
+        for (int d = 0; d <= a.ndims; ++d) {
+            if (d == a.kpos) { k = rest % a.K; rest /= a.K; }
+            if (d < a.ndims) {
+                i64 idx = rest % a.dn[d];
+                rest /= a.dn[d];
+                soff += idx * a.dis[d];
+                doff += idx * a.dos[d];
+            }
+        }
+        const double *S = a.src + soff;
+        double *D = a.dst + doff;
+#define SR(j) S[(j) * a.is_k]
+#define SI(j) S[(j) * a.is_k + a.src_im]
+#define DR(j) D[(j) * a.os_k]
+#define DI(j) D[(j) * a.os_k + a.dst_im]
+        switch (a.mode) {
+        case FFTW_AMD_R2R_PRE_HC2R: {
+            DR(k) = SR(k);
+            DI(k) = (k > 0 && 2 * k < n) ? SR(n - k) : 0.0;
+            break;
+        }
+        case FFTW_AMD_R2R_PRE_E10:
+        case FFTW_AMD_R2R_PRE_O10: {
+            i64 si = (k < (n + 1) / 2) ? 2 * k : 2 * n - 1 - 2 * k;
+            double v = SR(si);
+            if (a.mode == FFTW_AMD_R2R_PRE_O10 && (si & 1)) v = -v;
+            DR(k) = v;
+            break;
+        }
+        case FFTW_AMD_R2R_PRE_E01:
+        case FFTW_AMD_R2R_PRE_O01: {
+            double x, y;
+            if (a.mode == FFTW_AMD_R2R_PRE_E01) { x = SR(k); y = (k > 0) ? SR(n - k) : 0.0; }
+            else { x = SR(n - 1 - k); y = (k > 0) ? SR(k - 1) : 0.0; }
+            cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k);
+            DR(k) = x * w.x + y * w.y;
+            DI(k) = x * w.y - y * w.x;
+            break;
+        }
+        case FFTW_AMD_R2R_PRE_E00: {
+            i64 N = 2 * (n - 1);
+            DR(k) = SR(k < n ? k : N - k);
+            break;
+        }
+        case FFTW_AMD_R2R_PRE_O00: {
+            i64 N = 2 * (n + 1);
+            double v = 0.0;
+            if (k >= 1 && k <= n) v = SR(k - 1);
+            else if (k > n + 1) v = -SR(N - k - 1);
+            DR(k) = v;
+            break;
+        }
+        case FFTW_AMD_R2R_PRE_E11:
+        case FFTW_AMD_R2R_PRE_O11: {
+            double xr = SR(2 * k), xi = SR(n - 1 - 2 * k);
+            if (a.mode == FFTW_AMD_R2R_PRE_O11) { double t = xr; xr = xi; xi = t; }
+            cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 4 * k);
+            DR(k) = xr * w.x + xi * w.y;
+            DI(k) = xi * w.x - xr * w.y;
+            break;
+        }
+        case FFTW_AMD_R2R_PRE_E11ODD:
+        case FFTW_AMD_R2R_PRE_O11ODD: {
+            double re = 0.0, im = 0.0;
+            if (k < n) {
+                double x = (a.mode == FFTW_AMD_R2R_PRE_E11ODD) ? SR(k) : SR(n - 1 - k);
+                cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 2 * k);
+                re = x * w.x;
+                im = -x * w.y;
+            }
+            DR(k) = re;
+            DI(k) = im;
+            break;
+        }
+        case FFTW_AMD_R2R_POST_R2HC: {
+            DR(k) = SR(k);
+            if (k > 0 && 2 * k < n) DR(n - k) = SI(k);
+            break;
+        }
+        case FFTW_AMD_R2R_POST_DHT: {
+            double re = SR(k);
+            if (k > 0 && 2 * k < n) {
+                double im = SI(k);
+                DR(k) = re - im;
+                DR(n - k) = re + im;
+            } else {
+                DR(k) = re;
+            }
+            break;
+        }
+        case FFTW_AMD_R2R_POST_E10:
+        case FFTW_AMD_R2R_POST_O10: {
+            const bool rev = (a.mode == FFTW_AMD_R2R_POST_O10);
+            double vr = SR(k), vi = (k > 0 && 2 * k < n) ? SI(k) : 0.0;
+            cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k);
+            double dr = vr * w.x + vi * w.y, di = vi * w.x - vr * w.y;
+            DR(rev ? n - 1 - k : k) = 2.0 * dr;
+            if (k > 0 && 2 * k < n) DR(rev ? k - 1 : n - k) = -2.0 * di;
+            break;
+        }
+        case FFTW_AMD_R2R_POST_E01:
+        case FFTW_AMD_R2R_POST_O01: {
+            i64 di = (k < (n + 1) / 2) ? 2 * k : 2 * n - 1 - 2 * k;
+            double v = SR(k);
+            if (a.mode == FFTW_AMD_R2R_POST_O01 && (di & 1)) v = -v;
+            DR(di) = v;
+            break;
+        }
+        case FFTW_AMD_R2R_POST_E00:
+            DR(k) = SR(k);
+            break;
+        case FFTW_AMD_R2R_POST_O00:
+            DR(k) = -SI(k + 1);
+            break;
+        case FFTW_AMD_R2R_POST_E11:
+        case FFTW_AMD_R2R_POST_O11: {
+            double zr = SR(k), zi = SI(k);
+            cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 4 * k + 1);
+            double dr = zr * w.x + zi * w.y, di = zi * w.x - zr * w.y;
+            DR(2 * k) = 2.0 * dr;
+            DR(n - 1 - 2 * k) = (a.mode == FFTW_AMD_R2R_POST_O11) ? 2.0 * di : -2.0 * di;
+            break;
+        }
+        case FFTW_AMD_R2R_POST_E11ODD:
+        case FFTW_AMD_R2R_POST_O11ODD: {
+            double zr = SR(k), zi = SI(k);
+            cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 2 * k + 1);
+            double y = 2.0 * (zr * w.x + zi * w.y);
+            if (a.mode == FFTW_AMD_R2R_POST_O11ODD && (k & 1)) y = -y;
+            DR(k) = y;
+            break;
+        }
+        default:
+            break;
+        }
+#undef SR
+#undef SI
+#undef DR
+#undef DI
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* radix-4 r2c untangle / c2r tangle                                         */
 /* ------------------------------------------------------------------------ */
 /* n = 4m.  z_v[j] = x[4j+2v] + i x[4j+2v+1] (v = 0,1), Z_v = DFT_m(z_v) stored
@@ -1063,6 +1233,43 @@ extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bu
             hipLaunchKernelGGL(r2c_post4_kernel, grid, dim3(256), 0, st, ra);
         else
             hipLaunchKernelGGL(c2r_pre4_kernel, grid, dim3(256), 0, st, ra);
+        return 0;
+    }
+    case FFTW_AMD_STEP_R2R: {
+        R2RArgs ra;
+        int bd = d->batch_dim;
+        i64 sbase = d->src_base, dbase = d->dst_base;
+        for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+            ra.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+            ra.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+            ra.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+        }
+        if (bd >= 0) {
+            sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+            dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+            ra.dn[bd] = cn;
+        }
+        ra.src = bufs[d->src_buf] + sbase;
+        ra.dst = bufs[d->dst_buf] + dbase;
+        ra.src_im = d->src_im;
+        ra.dst_im = d->dst_im;
+        ra.is_k = d->is_l;
+        ra.os_k = d->os_l;
+        ra.n = d->aux_n;
+        ra.K = d->aux_valid;
+        ra.tw_lo = (d->tw_lo >= 0) ? (const cplx *)tables[d->tw_lo] : NULL;
+        ra.tw_hi = (d->tw_hi >= 0) ? (const cplx *)tables[d->tw_hi] : NULL;
+        ra.tw_shift = d->tw_shift;
+        ra.ndims = d->ndims;
+        ra.kpos = d->tile;
+        ra.mode = d->variant;
+        i64 total = ra.K;
+        for (int i = 0; i < d->ndims; ++i) total *= ra.dn[i];
+        ra.total = total;
+        if (total <= 0) return 0;
+        dim3 grid;
+        grid_for(total, &grid);
+        hipLaunchKernelGGL(r2r_kernel, grid, dim3(256), 0, st, ra);
         return 0;
     }
     case FFTW_AMD_STEP_RADER_MUL: {

@@ -466,9 +466,9 @@ static int loops_to_sdims(const fa_axis *ax, sdim *d, int use_dst_as_src) {
 /* dense scratch layout for an axis: batch loop outermost, then the remaining
    indices in the order of their source strides, innermost stride 2 (one
    interleaved complex).  Returns total doubles; fills axis and loop strides. */
-static i64 scratch_layout(const fa_axis *ax, i64 n_axis, i64 *ts_axis, i64 *ts_loop) {
+static i64 scratch_layout_u(const fa_axis *ax, i64 n_axis, i64 unit, i64 *ts_axis, i64 *ts_loop) {
     int order[FA_MAXLOOPS + 1], cnt = 0, i, j;
-    i64 key[FA_MAXLOOPS + 1], stride = 2;
+    i64 key[FA_MAXLOOPS + 1], stride = unit;
     /* index -1 denotes the axis itself */
     for (i = 0; i < ax->nloops; ++i) {
         if (i == ax->batch_loop) continue;
@@ -496,6 +496,10 @@ static i64 scratch_layout(const fa_axis *ax, i64 n_axis, i64 *ts_axis, i64 *ts_l
         stride *= ax->loops[ax->batch_loop].n;
     }
     return stride;
+}
+
+static i64 scratch_layout(const fa_axis *ax, i64 n_axis, i64 *ts_axis, i64 *ts_loop) {
+    return scratch_layout_u(ax, n_axis, 2, ts_axis, ts_loop);
 }
 
 /* Cooley-Tukey over k >= 2 passes through a scratch image:
@@ -1207,11 +1211,204 @@ static void build_c2r(plan *p) {
     if (cbuf >= 0) buf_release(p, cbuf);
 }
 
+
+/* ------------------------------------------------------------------ r2r */
+/* One r2r axis = PRE step (user reals -> inner input), an inner real or complex
+   DFT on scratch, POST step (inner output -> user reals).  The reference gets the
+   same transforms from R2HC/HC2R children with pre/post loops around them:
+   reodft010e-r2hc (fftw/fftw_api.c:12465-12660), redft00e-r2hc-pad (:11932-11965),
+   rodft00e-r2hc-pad (:14012-14050), reodft11e-radix2 (:13362-13640), reodft11e-r2hc-odd
+   (:13097-13230), dht-r2hc (:6365-6387).  Derivations of the index maps: DESIGN.md
+   section 9. */
+
+static fftw_amd_step_desc *emit_r2r_step(plan *p, int mode, i64 n, i64 K, i64 twmod,
+                                         fa_loc src, i64 is_k, fa_loc dst, i64 os_k,
+                                         const fa_axis *ax, const i64 *lis, const i64 *los,
+                                         int order_by_dst) {
+    fftw_amd_step_desc *s = new_step(p, FFTW_AMD_STEP_R2R);
+    sdim d[FA_MAXLOOPS];
+    int idx[FA_MAXLOOPS], cnt = 0, i, j, kpos = 0;
+    i64 key[FA_MAXLOOPS], akey = iabs(order_by_dst ? os_k : is_k);
+    s->variant = mode;
+    s->src_buf = src.buf; s->src_base = src.base; s->src_im = src.im;
+    s->dst_buf = dst.buf; s->dst_base = dst.base; s->dst_im = dst.im;
+    s->is_l = is_k;
+    s->os_l = os_k;
+    s->aux_n = n;
+    s->aux_valid = K;
+    if (twmod) tab_tw2(p, twmod, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+    /* flatten order: smallest user-side stride fastest, the batch loop last */
+    for (i = 0; i < ax->nloops; ++i) {
+        i64 k;
+        if (i == ax->batch_loop || ax->loops[i].n == 1) continue;
+        k = iabs(order_by_dst ? los[i] : lis[i]);
+        for (j = cnt - 1; j >= 0 && key[j] > k; --j) { idx[j + 1] = idx[j]; key[j + 1] = key[j]; }
+        idx[j + 1] = i;
+        key[j + 1] = k;
+        ++cnt;
+    }
+    for (i = 0; i < cnt; ++i) if (key[i] < akey) kpos = i + 1;
+    if (ax->batch_loop >= 0) idx[cnt++] = ax->batch_loop;
+    for (i = 0; i < cnt; ++i) {
+        d[i].n = ax->loops[idx[i]].n;
+        d[i].is = lis[idx[i]];
+        d[i].os = los[idx[i]];
+        d[i].tw = 0;
+        d[i].is_batch = (idx[i] == ax->batch_loop);
+    }
+    step_set_dims(p, s, d, cnt, -1);
+    s->tile = kpos;
+    p->est_flops += 4.0 * (double)K;
+    return s;
+}
+
+/* ax: loops with .is = user source strides, .os = user destination strides */
+static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc in, i64 rs,
+                          fa_loc out, i64 os) {
+    enum { IN_R2C, IN_C2R, IN_C2C };
+    int pre = 0, post = 0, inner = IN_R2C, j, nl = axp->nloops;
+    i64 N = n, cntA = 0, unitA = 1, cntB = 0, unitB = 1, twmod = 0, Kpre = 0, Kpost = 0;
+    i64 lis_user[FA_MAXLOOPS], los_user[FA_MAXLOOPS], ltsA[FA_MAXLOOPS], ltsB[FA_MAXLOOPS];
+    i64 tsA = 0, tsB = 0;
+    int abuf = -1, bbuf = -1;
+    fa_loc A = { -1, 0, 1 }, B = { -1, 0, 1 };
+    fa_axis lay, iax;
+    for (j = 0; j < nl; ++j) { lis_user[j] = axp->loops[j].is; los_user[j] = axp->loops[j].os; }
+
+    switch (kind) {
+    case FFTW_R2HC: post = FFTW_AMD_R2R_POST_R2HC; goto via_r2c;
+    case FFTW_DHT:  post = FFTW_AMD_R2R_POST_DHT;
+    via_r2c:
+        inner = IN_R2C; N = n; cntB = n / 2 + 1; unitB = 2; Kpost = n / 2 + 1;
+        break;
+    case FFTW_HC2R:
+        pre = FFTW_AMD_R2R_PRE_HC2R; inner = IN_C2R; N = n; cntA = n / 2 + 1; unitA = 2; Kpre = n / 2 + 1;
+        break;
+    case FFTW_REDFT10: pre = FFTW_AMD_R2R_PRE_E10; post = FFTW_AMD_R2R_POST_E10; goto makhoul_f;
+    case FFTW_RODFT10: pre = FFTW_AMD_R2R_PRE_O10; post = FFTW_AMD_R2R_POST_O10;
+    makhoul_f:
+        inner = IN_R2C; N = n; cntA = n; unitA = 1; cntB = n / 2 + 1; unitB = 2;
+        Kpre = n; Kpost = n / 2 + 1; twmod = 4 * n;
+        break;
+    case FFTW_REDFT01: pre = FFTW_AMD_R2R_PRE_E01; post = FFTW_AMD_R2R_POST_E01; goto makhoul_b;
+    case FFTW_RODFT01: pre = FFTW_AMD_R2R_PRE_O01; post = FFTW_AMD_R2R_POST_O01;
+    makhoul_b:
+        inner = IN_C2R; N = n; cntA = n / 2 + 1; unitA = 2; cntB = n; unitB = 1;
+        Kpre = n / 2 + 1; Kpost = n; twmod = 4 * n;
+        break;
+    case FFTW_REDFT00:
+        if (n < 2) { p->failed = 1; return; }
+        pre = FFTW_AMD_R2R_PRE_E00; post = FFTW_AMD_R2R_POST_E00;
+        inner = IN_R2C; N = 2 * (n - 1); cntA = N; unitA = 1; cntB = N / 2 + 1; unitB = 2;
+        Kpre = N; Kpost = n;
+        break;
+    case FFTW_RODFT00:
+        pre = FFTW_AMD_R2R_PRE_O00; post = FFTW_AMD_R2R_POST_O00;
+        inner = IN_R2C; N = 2 * (n + 1); cntA = N; unitA = 1; cntB = N / 2 + 1; unitB = 2;
+        Kpre = N; Kpost = n;
+        break;
+    case FFTW_REDFT11:
+    case FFTW_RODFT11: {
+        int odd = (kind == FFTW_RODFT11);
+        inner = IN_C2C; twmod = 8 * n; unitA = 2;
+        if (n % 2 == 0) {
+            pre = odd ? FFTW_AMD_R2R_PRE_O11 : FFTW_AMD_R2R_PRE_E11;
+            post = odd ? FFTW_AMD_R2R_POST_O11 : FFTW_AMD_R2R_POST_E11;
+            N = n / 2; cntA = N; Kpre = N; Kpost = N;
+        } else {
+            pre = odd ? FFTW_AMD_R2R_PRE_O11ODD : FFTW_AMD_R2R_PRE_E11ODD;
+            post = odd ? FFTW_AMD_R2R_POST_O11ODD : FFTW_AMD_R2R_POST_E11ODD;
+            N = 2 * n; cntA = N; Kpre = N; Kpost = n;
+        }
+        break;
+    }
+    default:
+        p->failed = 1;
+        return;
+    }
+
+    if (cntA) {
+        i64 total;
+        lay = *axp;
+        lay.is = rs;
+        total = scratch_layout_u(&lay, cntA, unitA, &tsA, ltsA);
+        abuf = buf_acquire(p, total);
+        A.buf = abuf;
+    }
+    if (cntB) {
+        i64 total;
+        lay = *axp;
+        lay.is = os;
+        for (j = 0; j < nl; ++j) lay.loops[j].is = los_user[j];
+        total = scratch_layout_u(&lay, cntB, unitB, &tsB, ltsB);
+        bbuf = buf_acquire(p, total);
+        B.buf = bbuf;
+    }
+
+    if (pre) emit_r2r_step(p, pre, n, Kpre, twmod, in, rs, A, tsA, axp, lis_user, ltsA, 0);
+
+    iax = *axp;
+    iax.flags_in = iax.flags_out = 0;
+    iax.dense = 0;
+    if (inner == IN_R2C) {
+        fa_loc s = pre ? A : in;
+        for (j = 0; j < nl; ++j) { iax.loops[j].is = pre ? ltsA[j] : lis_user[j]; iax.loops[j].os = ltsB[j]; }
+        s.im = 0;
+        emit_r2c_axis(p, N, &iax, s, pre ? tsA : rs, B, tsB);
+    } else if (inner == IN_C2R) {
+        fa_loc d = post ? B : out;
+        for (j = 0; j < nl; ++j) { iax.loops[j].is = ltsA[j]; iax.loops[j].os = post ? ltsB[j] : los_user[j]; }
+        d.im = 0;
+        emit_c2r_axis(p, N, &iax, A, tsA, d, post ? tsB : os);
+    } else {
+        for (j = 0; j < nl; ++j) { iax.loops[j].is = ltsA[j]; iax.loops[j].os = ltsA[j]; }
+        iax.n = N; iax.is = tsA; iax.os = tsA;
+        iax.src = A; iax.dst = A;
+        fa_emit_axis(p, &iax);
+        B = A; tsB = tsA;
+        for (j = 0; j < nl; ++j) ltsB[j] = ltsA[j];
+    }
+
+    if (post) emit_r2r_step(p, post, n, Kpost, twmod, B, tsB, out, os, axp, ltsB, los_user, 1);
+    if (abuf >= 0) buf_release(p, abuf);
+    if (bbuf >= 0) buf_release(p, bbuf);
+}
+
+/* separable r2r: every dim gets its own kind (reference problem_rdft with
+   kind[] per dim, fftw/fftw_api.c:9100-9150); the first processed axis moves the
+   data from the input to the output array, the others work in place there */
+static void build_r2r(plan *p) {
+    int a, first = 1;
+    fa_loc in = { 0, 0, 0 }, out = { 1, 0, 0 };
+    if (p->rank == 0) {
+        /* rank 0: strided copy of reals (reference rdft rank0 solver, fftw/fftw_api.c:9655-9720) */
+        fa_axis ax;
+        sdim d[FA_MAXLOOPS];
+        int nd;
+        memset(&ax, 0, sizeof(ax));
+        if (collect_loops(p, p->dims, 0, -1, NULL, 0, &ax)) { p->failed = 1; return; }
+        nd = loops_to_sdims(&ax, d, 0);
+        emit_copy(p, FFTW_AMD_STEP_COPY, in, out, 1, 1, 0, 0, d, nd,
+                  FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT, -1, -1);
+        return;
+    }
+    for (a = p->rank - 1; a >= 0; --a) {
+        fa_axis ax;
+        memset(&ax, 0, sizeof(ax));
+        if (collect_loops(p, p->dims, p->rank, a, NULL, !first, &ax)) { p->failed = 1; return; }
+        emit_r2r_axis(p, p->kinds[a], p->dims[a].n, &ax, first ? in : out,
+                      first ? p->dims[a].is : p->dims[a].os, out, p->dims[a].os);
+        if (p->failed) return;
+        first = 0;
+    }
+}
+
 static void build_steps(plan *p) {
     switch (p->type) {
     case FA_C2C: build_c2c(p); break;
     case FA_R2C: build_r2c(p); break;
     case FA_C2R: build_c2r(p); break;
+    case FA_R2R: build_r2r(p); break;
     default: p->failed = 1;
     }
 }
@@ -1375,8 +1572,8 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
     if (p->batch == 0) return;
     if (fa_device_init(p)) abort();
 
-    if (p->type == FA_R2C) in_im = 0;
-    if (p->type == FA_C2R) out_im = 0;
+    if (FA_REAL_IN(p->type)) in_im = 0;
+    if (FA_REAL_OUT(p->type)) out_im = 0;
 
     /* plain host arrays are staged through device copies (slow path, PCIe) */
     in_host = !fa_hip_is_device_ptr(ri);
@@ -1510,8 +1707,8 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
                     if (i == p->split) fa_hip_stream_wait_event(st, p->ev_a[slot]);
                 }
                 /* split-array callers may pass different re/im distances per call */
-                if (d.src_buf == 0 && p->type != FA_R2C && d.src_im == p->in_im) d.src_im = in_im;
-                if (d.dst_buf == 1 && p->type != FA_C2R && d.dst_im == p->out_im) d.dst_im = out_im;
+                if (d.src_buf == 0 && !FA_REAL_IN(p->type) && d.src_im == p->in_im) d.src_im = in_im;
+                if (d.dst_buf == 1 && !FA_REAL_OUT(p->type) && d.dst_im == p->out_im) d.dst_im = out_im;
                 if (events) { events[ev] = fa_hip_event_create(); fa_hip_event_record(events[ev++], st); }
                 if (fa_hip_launch_step(&d, sb, tabs, cs, cn, st)) abort();
                 if (events) { events[ev] = fa_hip_event_create(); fa_hip_event_record(events[ev++], st); }
@@ -1578,6 +1775,7 @@ static const char *kind_name(int k) {
     case FFTW_AMD_STEP_HERM_EXPAND: return "herm-expand";
     case FFTW_AMD_STEP_R2C_POST4: return "r2c-untangle4";
     case FFTW_AMD_STEP_C2R_PRE4: return "c2r-tangle4";
+    case FFTW_AMD_STEP_R2R: return "r2r";
     }
     return "?";
 }
@@ -1588,7 +1786,7 @@ char *fa_sprint(const plan *p) {
     size_t cap = 256 + (size_t)p->nsteps * 256, len = 0;
     char *s = (char *)malloc(cap);
     int i, j;
-    const char *tn = p->type == FA_C2C ? "dft" : p->type == FA_R2C ? "rdft2-r2c" : "rdft2-c2r";
+    const char *tn = p->type == FA_C2C ? "dft" : p->type == FA_R2C ? "rdft2-r2c" : p->type == FA_C2R ? "rdft2-c2r" : "rdft-r2r";
     len += (size_t)snprintf(s + len, cap - len, "(hip-%s batch=%lld chunk=%lld", tn, p->batch, p->chunk);
     for (i = 0; i < p->nsteps; ++i) {
         const fftw_amd_step_desc *d = &p->steps[i];
@@ -1607,6 +1805,13 @@ char *fa_sprint(const plan *p) {
             }
             len += (size_t)snprintf(s + len, cap - len, " tile=%d", d->tile);
             if (d->tw_n) len += (size_t)snprintf(s + len, cap - len, " tw=%lld", d->tw_n);
+        } else if (d->kind == FFTW_AMD_STEP_R2R) {
+            static const char *mn[] = { "?", "pre-hc2r", "pre-e10", "pre-o10", "pre-e01", "pre-o01", "pre-e00",
+                "pre-o00", "pre-e11", "pre-o11", "pre-e11odd", "pre-o11odd", "post-r2hc", "post-dht",
+                "post-e10", "post-o10", "post-e01", "post-o01", "post-e00", "post-o00", "post-e11",
+                "post-o11", "post-e11odd", "post-o11odd" };
+            int m = (d->variant >= 1 && d->variant <= FFTW_AMD_R2R_POST_O11ODD) ? d->variant : 0;
+            len += (size_t)snprintf(s + len, cap - len, "-%s n=%lld", mn[m], d->aux_n);
         } else {
             len += (size_t)snprintf(s + len, cap - len, " n=%lld", d->aux_n);
         }

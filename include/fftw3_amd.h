@@ -91,7 +91,28 @@ enum {
     FFTW_AMD_STEP_RADER_MUL = 5,/* Rader pointwise product and DC fix-ups */
     FFTW_AMD_STEP_HERM_EXPAND = 6,/* half spectrum -> full Hermitian spectrum */
     FFTW_AMD_STEP_R2C_POST4 = 7,  /* radix-4 untangle: two quarter-length complex DFTs -> r2c output */
-    FFTW_AMD_STEP_C2R_PRE4 = 8    /* inverse of the above */
+    FFTW_AMD_STEP_C2R_PRE4 = 8,   /* inverse of the above */
+    FFTW_AMD_STEP_R2R = 9         /* r2r pre/post-processing around a real or complex DFT; variant = FFTW_AMD_R2R_* */
+};
+
+/* FFTW_AMD_STEP_R2R modes (step.variant).  aux_n = r2r length n, aux_valid =
+   work items per transform, tile = position of the transform index among the
+   flattened loop indices, tw_* = two-level table of modulus 4n (01/10) or 8n (11).
+   PRE_* map the user's real array into the inner transform's input, POST_* map
+   the inner transform's output into the user's real array. */
+enum {
+    FFTW_AMD_R2R_PRE_HC2R = 1,   /* halfcomplex -> interleaved half spectrum */
+    FFTW_AMD_R2R_PRE_E10, FFTW_AMD_R2R_PRE_O10,     /* even/odd index shuffle (sign flips for RODFT10) */
+    FFTW_AMD_R2R_PRE_E01, FFTW_AMD_R2R_PRE_O01,     /* twiddled half spectrum for c2r */
+    FFTW_AMD_R2R_PRE_E00, FFTW_AMD_R2R_PRE_O00,     /* even / odd symmetric extension */
+    FFTW_AMD_R2R_PRE_E11, FFTW_AMD_R2R_PRE_O11,     /* n even: n/2 twiddled complex pairs */
+    FFTW_AMD_R2R_PRE_E11ODD, FFTW_AMD_R2R_PRE_O11ODD, /* n odd: twiddle and zero-pad to 2n */
+    FFTW_AMD_R2R_POST_R2HC, FFTW_AMD_R2R_POST_DHT,
+    FFTW_AMD_R2R_POST_E10, FFTW_AMD_R2R_POST_O10,
+    FFTW_AMD_R2R_POST_E01, FFTW_AMD_R2R_POST_O01,
+    FFTW_AMD_R2R_POST_E00, FFTW_AMD_R2R_POST_O00,
+    FFTW_AMD_R2R_POST_E11, FFTW_AMD_R2R_POST_O11,
+    FFTW_AMD_R2R_POST_E11ODD, FFTW_AMD_R2R_POST_O11ODD
 };
 
 enum {

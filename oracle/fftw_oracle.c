@@ -550,3 +550,217 @@ int oracle_c2r_many(int rank, const int *n, int howmany,
     free(x); free(y);
     return 0;
 }
+
+/* ------------------------------------------------------------------ r2r */
+/* r2r kinds, same numbering as fftw/fftw3.h:108-112 */
+enum { K_R2HC = 0, K_HC2R, K_DHT, K_REDFT00, K_REDFT01, K_REDFT10, K_REDFT11,
+       K_RODFT00, K_RODFT01, K_RODFT10, K_RODFT11 };
+
+/* One row of an r2r transform, restating how the reference's own accuracy test
+   defines every kind: as a DFT of logical size n0 of a sequence made real and
+   even/odd by the constraint functions mkre00 / mkro00 / mkre01 / mkro01 /
+   mkre10 / mkio10 / mkre11 / mkro11 (fftw/libbench2/verify-r2r.c:703-800), with
+   the sample placement and the 1/2 scalings of r2r_apply (:802-925) and
+   n0 = n, 2(n-1), 2(n+1), 4n or 8n (accuracy_r2r :944-955).  The size-n0 real
+   DFT is r2c_row above, i.e. the pinned complex path. */
+static int r2r_row(int kind, i64 n, const double *x, double *y) {
+    i64 n0, j, k;
+    double *e;
+    cx *F;
+    switch (kind) {
+    case K_R2HC: case K_DHT: case K_HC2R: n0 = n; break;
+    case K_REDFT00: if (n < 2) return -1; n0 = 2 * (n - 1); break;
+    case K_RODFT00: n0 = 2 * (n + 1); break;
+    case K_REDFT01: case K_REDFT10: case K_RODFT01: case K_RODFT10: n0 = 4 * n; break;
+    case K_REDFT11: case K_RODFT11: n0 = 8 * n; break;
+    default: return -1;
+    }
+    e = (double *)calloc((size_t)n0, sizeof(double));
+    F = (cx *)malloc(sizeof(cx) * (size_t)(n0 / 2 + 1));
+    if (kind == K_HC2R) {
+        /* halfcomplex r0 r1 .. r(n/2) i((n+1)/2-1) .. i1 -> Hermitian spectrum, backward DFT */
+        for (k = 0; k <= n / 2; ++k) {
+            double im = (k > 0 && 2 * k < n) ? x[n - k] : 0.0;
+            F[k] = x[k] + I * im;
+        }
+        c2r_row(n, F, y);
+        free(e); free(F);
+        return 0;
+    }
+    switch (kind) {
+    case K_R2HC: case K_DHT:
+        for (j = 0; j < n; ++j) e[j] = x[j];
+        break;
+    case K_REDFT00:                       /* even about 0 and n-1 */
+        for (j = 0; j < n; ++j) { e[j] = x[j]; e[(n0 - j) % n0] = x[j]; }
+        break;
+    case K_RODFT00:                       /* odd about -1 and n */
+        for (j = 0; j < n; ++j) { e[j + 1] = x[j]; e[n0 - 1 - j] = -x[j]; }
+        break;
+    case K_REDFT10:                       /* samples at odd points of the 4n grid, even */
+        for (j = 0; j < n; ++j) { e[2 * j + 1] = x[j]; e[n0 - 2 * j - 1] = x[j]; }
+        break;
+    case K_RODFT10:                       /* the same, odd */
+        for (j = 0; j < n; ++j) { e[2 * j + 1] = x[j]; e[n0 - 2 * j - 1] = -x[j]; }
+        break;
+    case K_REDFT01:                       /* even about 0, odd about n (mkre01) */
+        for (j = 0; j < n; ++j) {
+            e[j] = x[j];
+            e[2 * n - j] = -x[j];
+        }
+        e[n] = 0.0;
+        for (j = 1; j < 2 * n; ++j) e[n0 - j] = e[j];
+        break;
+    case K_RODFT01:                       /* odd about 0, even about n (mkro01) */
+        for (j = 0; j < n; ++j) {
+            e[j + 1] = x[j];
+            e[2 * n - j - 1] = x[j];
+        }
+        for (j = 1; j < 2 * n; ++j) e[n0 - j] = -e[j];
+        break;
+    case K_REDFT11:                       /* odd points of the 8n grid; odd about 2n, even about 0 (mkre11) */
+        for (j = 0; j < n; ++j) {
+            e[2 * j + 1] = x[j];
+            e[4 * n - 2 * j - 1] = -x[j];
+        }
+        for (j = 1; j < 4 * n; ++j) e[n0 - j] = e[j];
+        break;
+    case K_RODFT11:                       /* even about 2n, odd about 0 (mkro11) */
+        for (j = 0; j < n; ++j) {
+            e[2 * j + 1] = x[j];
+            e[4 * n - 2 * j - 1] = x[j];
+        }
+        for (j = 1; j < 4 * n; ++j) e[n0 - j] = -e[j];
+        break;
+    }
+    r2c_row(n0, e, F);
+    switch (kind) {
+    case K_R2HC:
+        for (k = 0; k <= n / 2; ++k) {
+            y[k] = creal(F[k]);
+            if (k > 0 && 2 * k < n) y[n - k] = cimag(F[k]);
+        }
+        break;
+    case K_DHT:
+        for (k = 0; k <= n / 2; ++k) {
+            y[k] = creal(F[k]) - cimag(F[k]);
+            if (k > 0 && 2 * k < n) y[n - k] = creal(F[k]) + cimag(F[k]);
+        }
+        break;
+    case K_REDFT00: for (k = 0; k < n; ++k) y[k] = creal(F[k]); break;
+    case K_RODFT00: for (k = 0; k < n; ++k) y[k] = -cimag(F[k + 1]); break;
+    case K_REDFT10: for (k = 0; k < n; ++k) y[k] = creal(F[k]); break;
+    case K_RODFT10: for (k = 0; k < n; ++k) y[k] = -cimag(F[k + 1]); break;
+    case K_REDFT01: case K_REDFT11: for (k = 0; k < n; ++k) y[k] = 0.5 * creal(F[2 * k + 1]); break;
+    case K_RODFT01: case K_RODFT11: for (k = 0; k < n; ++k) y[k] = -0.5 * cimag(F[2 * k + 1]); break;
+    }
+    free(e); free(F);
+    return 0;
+}
+
+/* The same kinds straight from their defining sums, O(n^2), with the exactly
+   reduced trig of the reference's verifier (cos00 .. sin11,
+   fftw/libbench2/verify-r2r.c:104-146; definitions fftw/doc/reference.texi:1905-2000
+   halfcomplex, :2058-2130 DCTs, :2150-2230 DSTs, :2245-2270 DHT).  Cross-check
+   for r2r_row. */
+int oracle_r2r_direct(int kind, int n_, const double *x, double *y) {
+    i64 n = n_, j, k;
+    double w[2];
+#define COS2PI(m, N) (oracle_cexp((m), (N), w), w[0])
+#define SIN2PI(m, N) (oracle_cexp((m), (N), w), w[1])
+    for (k = 0; k < n; ++k) {
+        long double acc = 0.0L;
+        switch (kind) {
+        case K_R2HC:
+            if (2 * k <= n) { for (j = 0; j < n; ++j) acc += x[j] * COS2PI(j * k, n); }
+            else { for (j = 0; j < n; ++j) acc -= x[j] * SIN2PI(j * (n - k), n); }
+            break;
+        case K_HC2R:
+            acc = x[0];
+            for (j = 1; 2 * j < n; ++j)
+                acc += 2.0L * (x[j] * COS2PI(j * k, n) - x[n - j] * SIN2PI(j * k, n));
+            if (n % 2 == 0 && n > 1) acc += x[n / 2] * ((k & 1) ? -1.0 : 1.0);
+            break;
+        case K_DHT:
+            for (j = 0; j < n; ++j) { oracle_cexp(j * k, n, w); acc += x[j] * ((long double)w[0] + w[1]); }
+            break;
+        case K_REDFT00:
+            if (n < 2) return -1;
+            acc = x[0] + ((k & 1) ? -x[n - 1] : x[n - 1]);
+            for (j = 1; j < n - 1; ++j) acc += 2.0L * x[j] * COS2PI(j * k, 2 * (n - 1));
+            break;
+        case K_REDFT10:
+            for (j = 0; j < n; ++j) acc += 2.0L * x[j] * COS2PI((2 * j + 1) * k, 4 * n);
+            break;
+        case K_REDFT01:
+            acc = x[0];
+            for (j = 1; j < n; ++j) acc += 2.0L * x[j] * COS2PI(j * (2 * k + 1), 4 * n);
+            break;
+        case K_REDFT11:
+            for (j = 0; j < n; ++j) acc += 2.0L * x[j] * COS2PI((2 * j + 1) * (2 * k + 1), 8 * n);
+            break;
+        case K_RODFT00:
+            for (j = 0; j < n; ++j) acc += 2.0L * x[j] * SIN2PI((j + 1) * (k + 1), 2 * (n + 1));
+            break;
+        case K_RODFT10:
+            for (j = 0; j < n; ++j) acc += 2.0L * x[j] * SIN2PI((2 * j + 1) * (k + 1), 4 * n);
+            break;
+        case K_RODFT01:
+            acc = (k & 1) ? -x[n - 1] : x[n - 1];
+            for (j = 0; j < n - 1; ++j) acc += 2.0L * x[j] * SIN2PI((j + 1) * (2 * k + 1), 4 * n);
+            break;
+        case K_RODFT11:
+            for (j = 0; j < n; ++j) acc += 2.0L * x[j] * SIN2PI((2 * j + 1) * (2 * k + 1), 8 * n);
+            break;
+        default:
+            return -1;
+        }
+        y[k] = (double)acc;
+    }
+#undef COS2PI
+#undef SIN2PI
+    return 0;
+}
+
+/* fftw_plan_many_r2r + fftw_execute: kind[d] along dim d, separably
+   (reference problem_rdft, fftw/fftw_api.c:9100-9150, API :816-838) */
+int oracle_r2r_many(int rank, const int *n, int howmany,
+                    const double *in, const int *inembed, int istride, int idist,
+                    double *out, const int *onembed, int ostride, int odist, const int *kind) {
+    i64 nn[16], ie[16], oe[16], total = 1, f, maxn = 1;
+    int d, b, rc = 0;
+    double *a, *ti, *to;
+    if (rank < 0 || rank > 16 || howmany < 0) return -1;
+    cache_gc();
+    for (d = 0; d < rank; ++d) {
+        if (n[d] <= 0) return -1;
+        nn[d] = n[d];
+        ie[d] = inembed ? inembed[d] : n[d];
+        oe[d] = onembed ? onembed[d] : n[d];
+        total *= n[d];
+        if (n[d] > maxn) maxn = n[d];
+    }
+    a = (double *)malloc(sizeof(double) * (size_t)total);
+    ti = (double *)malloc(sizeof(double) * (size_t)maxn);
+    to = (double *)malloc(sizeof(double) * (size_t)maxn);
+    for (b = 0; b < howmany && !rc; ++b) {
+        const double *ib = in + (i64)b * idist;
+        double *ob = out + (i64)b * odist;
+        i64 stride = 1;
+        for (f = 0; f < total; ++f) a[f] = ib[embed_off(rank, nn, ie, f, istride)];
+        for (d = rank - 1; d >= 0 && !rc; --d) {
+            i64 outer = total / (nn[d] * stride), o, s, j;
+            for (o = 0; o < outer && !rc; ++o)
+                for (s = 0; s < stride && !rc; ++s) {
+                    double *base = a + o * nn[d] * stride + s;
+                    for (j = 0; j < nn[d]; ++j) ti[j] = base[j * stride];
+                    rc = r2r_row(kind[d], nn[d], ti, to);
+                    for (j = 0; j < nn[d]; ++j) base[j * stride] = to[j];
+                }
+            stride *= nn[d];
+        }
+        for (f = 0; f < total; ++f) ob[embed_off(rank, nn, oe, f, ostride)] = a[f];
+    }
+    free(a); free(ti); free(to);
+    return rc;
+}

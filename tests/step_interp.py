@@ -287,8 +287,123 @@ class Interp(object):
                 work[a:a + 2 * pm1:2] = P.real
                 work[a + 1:a + 2 * pm1:2] = P.imag
                 _store(dst, np.array([doffs[v]]), s.dst_im, s.flags, np.array([x0 + A[0]]))
+        elif s.kind == fa.STEP_R2R:
+            self._r2r(s, src, dst, dn, dis, dos, sbase, dbase)
         else:
             raise AssertionError("unknown step kind %d" % s.kind)
+
+    def _r2r(self, s, src, dst, dn, dis, dos, sbase, dbase):
+        """FFTW_AMD_STEP_R2R as specified in include/fftw3_amd.h / DESIGN.md section 9"""
+        n, K, mode = s.aux_n, s.aux_valid, s.variant
+        g = _grids([K] + dn)
+        k, idx = g[0], g[1:]
+        soff = np.zeros_like(k) + sbase
+        doff = np.zeros_like(k) + dbase
+        for i, gi in enumerate(idx):
+            soff = soff + gi * dis[i]
+            doff = doff + gi * dos[i]
+        full = np.broadcast(soff, doff).shape
+        k = np.broadcast_to(k, full)
+        soff = np.broadcast_to(soff, full)
+        doff = np.broadcast_to(doff, full)
+
+        def SR(j, mask=None):
+            j = np.broadcast_to(j, full)
+            if mask is None:
+                return src[soff + j * s.is_l]
+            return np.where(mask, src[soff + np.where(mask, j, 0) * s.is_l], 0.0)
+
+        def SI(j, mask=None):
+            j = np.broadcast_to(j, full)
+            if mask is None:
+                return src[soff + j * s.is_l + s.src_im]
+            return np.where(mask, src[soff + np.where(mask, j, 0) * s.is_l + s.src_im], 0.0)
+
+        def DR(j, v, mask=None):
+            j = np.broadcast_to(j, full)
+            v = np.broadcast_to(v, full)
+            if mask is None:
+                dst[doff + j * s.os_l] = v
+            else:
+                dst[(doff + j * s.os_l)[mask]] = v[mask]
+
+        def DI(j, v):
+            dst[doff + np.broadcast_to(j, full) * s.os_l + s.dst_im] = np.broadcast_to(v, full)
+
+        mid = (k > 0) & (2 * k < n)
+        if mode == fa.R2R_PRE_HC2R:
+            re, im = SR(k), SR(n - k, mid)
+            DR(k, re); DI(k, im)
+        elif mode in (fa.R2R_PRE_E10, fa.R2R_PRE_O10):
+            si = np.where(k < (n + 1) // 2, 2 * k, 2 * n - 1 - 2 * k)
+            v = SR(si)
+            if mode == fa.R2R_PRE_O10:
+                v = np.where(si & 1, -v, v)
+            DR(k, v)
+        elif mode in (fa.R2R_PRE_E01, fa.R2R_PRE_O01):
+            if mode == fa.R2R_PRE_E01:
+                x, y = SR(k), SR(n - k, k > 0)
+            else:
+                x, y = SR(n - 1 - k), SR(k - 1, k > 0)
+            w = self.tw2(s, k)
+            v = w * (x - 1j * y)
+            DR(k, v.real); DI(k, v.imag)
+        elif mode == fa.R2R_PRE_E00:
+            DR(k, SR(np.where(k < n, k, 2 * (n - 1) - k)))
+        elif mode == fa.R2R_PRE_O00:
+            N = 2 * (n + 1)
+            a = SR(k - 1, (k >= 1) & (k <= n))
+            b = SR(N - k - 1, k > n + 1)
+            DR(k, a - b)
+        elif mode in (fa.R2R_PRE_E11, fa.R2R_PRE_O11):
+            xr, xi = SR(2 * k), SR(n - 1 - 2 * k)
+            if mode == fa.R2R_PRE_O11:
+                xr, xi = xi, xr
+            v = (xr + 1j * xi) * np.conj(self.tw2(s, 4 * k))
+            DR(k, v.real); DI(k, v.imag)
+        elif mode in (fa.R2R_PRE_E11ODD, fa.R2R_PRE_O11ODD):
+            lo = k < n
+            x = SR(k, lo) if mode == fa.R2R_PRE_E11ODD else SR(n - 1 - k, lo)
+            v = x * np.conj(self.tw2(s, np.where(lo, 2 * k, 0)))
+            DR(k, v.real); DI(k, v.imag)
+        elif mode == fa.R2R_POST_R2HC:
+            re, im = SR(k), SI(k, mid)
+            DR(k, re)
+            DR(n - k, im, mid)
+        elif mode == fa.R2R_POST_DHT:
+            re, im = SR(k), SI(k, mid)
+            DR(k, re - im)
+            DR(n - k, re + im, mid)
+        elif mode in (fa.R2R_POST_E10, fa.R2R_POST_O10):
+            v = (SR(k) + 1j * SI(k, mid)) * np.conj(self.tw2(s, k))
+            if mode == fa.R2R_POST_E10:
+                DR(k, 2 * v.real)
+                DR(n - k, -2 * v.imag, mid)
+            else:
+                DR(n - 1 - k, 2 * v.real)
+                DR(k - 1, -2 * v.imag, mid)
+        elif mode in (fa.R2R_POST_E01, fa.R2R_POST_O01):
+            di = np.where(k < (n + 1) // 2, 2 * k, 2 * n - 1 - 2 * k)
+            v = SR(k)
+            if mode == fa.R2R_POST_O01:
+                v = np.where(di & 1, -v, v)
+            DR(di, v)
+        elif mode == fa.R2R_POST_E00:
+            DR(k, SR(k))
+        elif mode == fa.R2R_POST_O00:
+            DR(k, -SI(k + 1))
+        elif mode in (fa.R2R_POST_E11, fa.R2R_POST_O11):
+            v = (SR(k) + 1j * SI(k)) * np.conj(self.tw2(s, 4 * k + 1))
+            DR(2 * k, 2 * v.real)
+            DR(n - 1 - 2 * k, 2 * v.imag if mode == fa.R2R_POST_O11 else -2 * v.imag)
+        elif mode in (fa.R2R_POST_E11ODD, fa.R2R_POST_O11ODD):
+            v = (SR(k) + 1j * SI(k)) * np.conj(self.tw2(s, 2 * k + 1))
+            y = 2 * v.real
+            if mode == fa.R2R_POST_O11ODD:
+                y = np.where(k & 1, -y, y)
+            DR(k, y)
+        else:
+            raise AssertionError("unknown r2r mode %d" % mode)
 
 
 def scratch_reals(plan):

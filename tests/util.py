@@ -24,6 +24,11 @@ def oracle():
                                         vp, ip, C.c_int, C.c_int]
         lib.oracle_c2r_many.argtypes = [C.c_int, ip, C.c_int, vp, ip, C.c_int, C.c_int,
                                         vp, ip, C.c_int, C.c_int]
+        lib.oracle_r2r_many.argtypes = [C.c_int, ip, C.c_int, vp, ip, C.c_int, C.c_int,
+                                        vp, ip, C.c_int, C.c_int, ip]
+        lib.oracle_r2r_many.restype = C.c_int
+        lib.oracle_r2r_direct.argtypes = [C.c_int, C.c_int, vp, vp]
+        lib.oracle_r2r_direct.restype = C.c_int
         lib.oracle_cexp.argtypes = [C.c_longlong, C.c_longlong, C.POINTER(C.c_double)]
         for f in (lib.oracle_dft_many, lib.oracle_r2c_many, lib.oracle_c2r_many):
             f.restype = C.c_int
@@ -81,6 +86,30 @@ def oracle_c2r(y, shape, howmany=1, out=None, inembed=None, istride=1, idist=Non
                                   _ints(onembed), ostride, odist)
     assert rc == 0
     return out
+
+
+def oracle_r2r(x, shape, kinds, howmany=1, out=None, inembed=None, istride=1, idist=None,
+               onembed=None, ostride=1, odist=None):
+    """fftw_plan_many_r2r + execute through the oracle; x, out: float64 arrays"""
+    n = int(np.prod(shape)) if len(shape) else 1
+    idist = n if idist is None else idist
+    odist = n if odist is None else odist
+    if out is None:
+        out = np.zeros(max(1, howmany) * n, dtype=np.float64)
+    x = np.ascontiguousarray(x)
+    rc = oracle().oracle_r2r_many(len(shape), _ints(list(shape)), howmany, x.ctypes.data,
+                                  _ints(inembed), istride, idist, out.ctypes.data,
+                                  _ints(onembed), ostride, odist, _ints(list(kinds)))
+    assert rc == 0
+    return out
+
+
+def oracle_r2r_direct(x, kind):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    rc = oracle().oracle_r2r_direct(kind, x.size, x.ctypes.data, y.ctypes.data)
+    assert rc == 0
+    return y
 
 
 def aerror(a, b):
