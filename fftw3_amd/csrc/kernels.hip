@@ -349,7 +349,76 @@ struct RealArgs {
     const cplx *tw_hi;
     int tw_shift;
     int ndims, flags;
+    int r2r;     /* fused r2r epilogue (r2c) / prologue (c2r): FFTW_AMD_R2R_* or 0 */
+    int twmul;   /* untangle twiddle w_n^k = table entry k * twmul */
+    i64 rn;      /* r2r length */
 };
+
+/* Fused r2r epilogue of the r2c untangle kernels: Y = half-spectrum entry idx of
+   the inner real DFT; what POST_* of r2r_kernel would do with it, without the
+   trip through memory.  D = destination row (reals of stride os_k). */
+template <class A>
+FA_DEV void epi_store(const A &a, i64 doff, i64 idx, cplx Y) {
+    if (a.r2r == 0) {
+        store_elem<false>(a.dst, doff + idx * a.os_k, a.dst_im, a.flags, Y);
+        return;
+    }
+    double *D = a.dst + doff;
+    const i64 n = a.rn;
+    const bool mid = (idx > 0 && 2 * idx < n);
+    switch (a.r2r) {
+    case FFTW_AMD_R2R_POST_R2HC:
+        D[idx * a.os_k] = Y.x;
+        if (mid) D[(n - idx) * a.os_k] = Y.y;
+        break;
+    case FFTW_AMD_R2R_POST_DHT:
+        if (mid) { D[idx * a.os_k] = Y.x - Y.y; D[(n - idx) * a.os_k] = Y.x + Y.y; }
+        else D[idx * a.os_k] = Y.x;
+        break;
+    case FFTW_AMD_R2R_POST_E10:
+    case FFTW_AMD_R2R_POST_O10: {
+        const bool rev = (a.r2r == FFTW_AMD_R2R_POST_O10);
+        cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, idx);
+        double vi = mid ? Y.y : 0.0;
+        double dr = Y.x * w.x + vi * w.y, di = vi * w.x - Y.x * w.y;
+        D[(rev ? n - 1 - idx : idx) * a.os_k] = 2.0 * dr;
+        if (mid) D[(rev ? idx - 1 : n - idx) * a.os_k] = -2.0 * di;
+        break;
+    }
+    case FFTW_AMD_R2R_POST_E00:
+        D[idx * a.os_k] = Y.x;
+        break;
+    case FFTW_AMD_R2R_POST_O00:
+        if (idx >= 1 && idx <= n) D[(idx - 1) * a.os_k] = -Y.y;
+        break;
+    default:
+        break;
+    }
+}
+
+/* Fused r2r prologue of the c2r tangle kernels: half-spectrum entry idx built
+   from the user's real r2r input S (stride is_k), as PRE_* of r2r_kernel would. */
+template <class A>
+FA_DEV cplx pro_load(const A &a, i64 soff, i64 idx) {
+    if (a.r2r == 0) return load_elem<false>(a.src, soff + idx * a.is_k, a.src_im, 0);
+    const double *S = a.src + soff;
+    const i64 n = a.rn;
+    switch (a.r2r) {
+    case FFTW_AMD_R2R_PRE_HC2R:
+        return c_make(S[idx * a.is_k], (idx > 0 && 2 * idx < n) ? S[(n - idx) * a.is_k] : 0.0);
+    case FFTW_AMD_R2R_PRE_E01:
+    case FFTW_AMD_R2R_PRE_O01: {
+        double x, y;
+        if (a.r2r == FFTW_AMD_R2R_PRE_E01) { x = S[idx * a.is_k]; y = (idx > 0) ? S[(n - idx) * a.is_k] : 0.0; }
+        else { x = S[(n - 1 - idx) * a.is_k]; y = (idx > 0) ? S[(idx - 1) * a.is_k] : 0.0; }
+        cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, idx);
+        return c_make(x * w.x + y * w.y, x * w.y - y * w.x);
+    }
+    default:
+        return c_make(0.0, 0.0);
+    }
+}
+
 
 /* Y[k] = E + w^k O, Y[h-k] = conj(E - w^k O), E = (Z[k] + conj Z[h-k]) / 2,
    O = -i (Z[k] - conj Z[h-k]) / 2   (the 1/2 is the
@@ -373,14 +442,14 @@ __global__ void __launch_bounds__(256) r2c_post_kernel(const RealArgs a) {
         cplx E = c_make(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
         cplx D = c_make(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
         cplx O = c_mni(D);
-        cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k);
+        cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k * a.twmul);
         cplx P = c_mulc(O, w);
         cplx yk = c_add(E, P);
         cplx ym = c_sub(E, P);
         ym.y = -ym.y;
         if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
-        store_elem<false>(a.dst, doff + k * a.os_k, a.dst_im, a.flags, yk);
-        if (km != k) store_elem<false>(a.dst, doff + km * a.os_k, a.dst_im, a.flags, ym);
+        epi_store(a, doff, k, yk);
+        if (km != k) epi_store(a, doff, km, ym);
     }
 }
 
@@ -401,12 +470,12 @@ __global__ void __launch_bounds__(256) c2r_pre_kernel(const RealArgs a) {
             doff += idx * a.dos[d];
         }
         i64 km = a.h - k;
-        cplx yk = load_elem<false>(a.src, soff + k * a.is_k, a.src_im, 0);
-        cplx ym = load_elem<false>(a.src, soff + km * a.is_k, a.src_im, 0);
+        cplx yk = pro_load(a, soff, k);
+        cplx ym = pro_load(a, soff, km);
         if (k == 0) { yk.y = 0.0; ym.y = 0.0; }   /* Im Y[0], Im Y[n/2] are ignored */
         cplx E = c_make(yk.x + ym.x, yk.y - ym.y);
         cplx D = c_make(yk.x - ym.x, yk.y + ym.y);
-        cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k);
+        cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k * a.twmul);
         cplx O = c_mul(D, w);
         cplx iO = c_mpi(O);
         cplx zk = c_add(E, iO);
@@ -611,6 +680,8 @@ struct Real4Args {
     const cplx *tw_hi;
     int tw_shift;
     int ndims, flags;
+    int r2r, twmul;      /* as in RealArgs */
+    i64 rn;
 };
 
 __global__ void __launch_bounds__(256) r2c_post4_kernel(const Real4Args a) {
@@ -637,9 +708,9 @@ __global__ void __launch_bounds__(256) r2c_post4_kernel(const Real4Args a) {
             T[2 * v] = E;
             T[2 * v + 1] = c_mni(D);
         }
-        T[1] = c_mulc(T[1], tw2(a.tw_lo, a.tw_hi, a.tw_shift, k));
-        T[2] = c_mulc(T[2], tw2(a.tw_lo, a.tw_hi, a.tw_shift, 2 * k));
-        T[3] = c_mulc(T[3], tw2(a.tw_lo, a.tw_hi, a.tw_shift, 3 * k));
+        T[1] = c_mulc(T[1], tw2(a.tw_lo, a.tw_hi, a.tw_shift, k * a.twmul));
+        T[2] = c_mulc(T[2], tw2(a.tw_lo, a.tw_hi, a.tw_shift, 2 * k * a.twmul));
+        T[3] = c_mulc(T[3], tw2(a.tw_lo, a.tw_hi, a.tw_shift, 3 * k * a.twmul));
         cplx s02 = c_add(T[0], T[2]), d02 = c_sub(T[0], T[2]);
         cplx s13 = c_add(T[1], T[3]), d13 = c_sub(T[1], T[3]);
         cplx y0 = c_add(s02, s13);                 /* Y[k]       */
@@ -647,10 +718,10 @@ __global__ void __launch_bounds__(256) r2c_post4_kernel(const Real4Args a) {
         cplx y2 = c_sub(s02, s13);  y2.y = -y2.y;  /* Y[2m-k]    */
         cplx y3 = c_add(d02, c_mpi(d13)); y3.y = -y3.y;   /* Y[m-k] */
         if (k == 0) { y0.y = 0.0; y2.y = 0.0; }
-        store_elem<false>(a.dst, doff + k * a.os_k, a.dst_im, a.flags, y0);
-        store_elem<false>(a.dst, doff + (k + m) * a.os_k, a.dst_im, a.flags, y1);
-        store_elem<false>(a.dst, doff + (2 * m - k) * a.os_k, a.dst_im, a.flags, y2);
-        if (k != 0 && 2 * k != m) store_elem<false>(a.dst, doff + (m - k) * a.os_k, a.dst_im, a.flags, y3);
+        epi_store(a, doff, k, y0);
+        epi_store(a, doff, k + m, y1);
+        epi_store(a, doff, 2 * m - k, y2);
+        if (k != 0 && 2 * k != m) epi_store(a, doff, m - k, y3);
     }
 }
 
@@ -684,14 +755,14 @@ __global__ void __launch_bounds__(256) c2r_pre4_kernel(const Real4Args a) {
         }
         const i64 m = a.m;
         /* the four half-spectrum entries this pair needs (src here is Y, is_k its stride) */
-        cplx Yk = load_elem<false>(a.src, soff + k * a.is_k, a.src_im, 0);
-        cplx Ykm = load_elem<false>(a.src, soff + (k + m) * a.is_k, a.src_im, 0);
-        cplx Y2 = load_elem<false>(a.src, soff + (2 * m - k) * a.is_k, a.src_im, 0);
-        cplx Y1 = load_elem<false>(a.src, soff + (m - k) * a.is_k, a.src_im, 0);
+        cplx Yk = pro_load(a, soff, k);
+        cplx Ykm = pro_load(a, soff, k + m);
+        cplx Y2 = pro_load(a, soff, 2 * m - k);
+        cplx Y1 = pro_load(a, soff, m - k);
         if (k == 0) { Yk.y = 0.0; Y2.y = 0.0; }      /* Im Y[0], Im Y[n/2] are ignored */
-        cplx w1 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k);
-        cplx w2 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 2 * k);
-        cplx w3 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 3 * k);
+        cplx w1 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, k * a.twmul);
+        cplx w2 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 2 * k * a.twmul);
+        cplx w3 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 3 * k * a.twmul);
         cplx z0, z1;
         c2r4_combine(Yk, Ykm, c_make(Y2.x, -Y2.y), c_make(Y1.x, -Y1.y), w1, w2, w3, &z0, &z1);
         store_elem<false>(a.dst, doff + k * a.os_k, a.dst_im, a.flags, z0);
@@ -1134,6 +1205,13 @@ static void fill_copy_args(CopyArgs *ca, const fftw_amd_step_desc *d, double *co
     ca->total = total;
 }
 
+/* r2r length n from the inner real-DFT length N of a fused step */
+static i64 r2r_len_of(int mode, i64 N) {
+    if (mode == FFTW_AMD_R2R_POST_E00) return N / 2 + 1;
+    if (mode == FFTW_AMD_R2R_POST_O00) return N / 2 - 1;
+    return N;
+}
+
 extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bufs,
                                   void *const *tables, long long cs, long long cn,
                                   void *stream) {
@@ -1177,6 +1255,9 @@ extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bu
         ra.os_k = d->os_l;
         ra.h = d->aux_n / 2;
         ra.npair = ra.h / 2 + 1;
+        ra.r2r = d->variant;
+        ra.twmul = d->tile > 0 ? d->tile : 1;
+        ra.rn = r2r_len_of(d->variant, d->aux_n);
         ra.tw_lo = (const cplx *)tables[d->tw_lo];
         ra.tw_hi = (const cplx *)tables[d->tw_hi];
         ra.tw_shift = d->tw_shift;
@@ -1217,6 +1298,9 @@ extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bu
         ra.os_k = d->os_l;
         ra.vs = d->aux_valid;            /* distance between the two quarter-length vectors */
         ra.m = d->aux_n / 4;
+        ra.r2r = d->variant;
+        ra.twmul = d->tile > 0 ? d->tile : 1;
+        ra.rn = r2r_len_of(d->variant, d->aux_n);
         ra.npair = (d->kind == FFTW_AMD_STEP_R2C_POST4) ? ra.m / 2 + 1 : ra.m / 2 + 1;
         ra.tw_lo = (const cplx *)tables[d->tw_lo];
         ra.tw_hi = (const cplx *)tables[d->tw_hi];

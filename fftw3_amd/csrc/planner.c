@@ -864,7 +864,30 @@ static int axis_pass_count(i64 n) {
 /* real -> half spectrum along one axis.  ax: the loops (.is = strides in the real
    source, .os = strides in the complex destination) and the batch loop; rs / cs:
    element strides of the transform index on the two sides, in doubles. */
-static void emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs, fa_loc out, i64 cs) {
+/* can the r2c / c2r axis emitters fuse an r2r epilogue / prologue for this length? */
+static int r2r_can_fuse(i64 nl) { return nl >= 2 && nl % 2 == 0 && !getenv("FFTW_AMD_R2R_UNFUSED"); }
+
+/* twiddle tables of an untangle / tangle step.  Plain: modulus nl.  With a fused
+   REDFT/RODFT 10/01 epilogue or prologue: the modulus-4n table serves both the
+   r2r twiddle w_4n^k and the untangle twiddle w_n^k = w_4n^(4k) (step.tile = 4 is
+   the index multiplier of the latter). */
+static void r2r_fuse_tables(plan *p, fftw_amd_step_desc *s, i64 nl, int mode) {
+    s->variant = mode;
+    if (mode == FFTW_AMD_R2R_POST_E10 || mode == FFTW_AMD_R2R_POST_O10 ||
+        mode == FFTW_AMD_R2R_PRE_E01 || mode == FFTW_AMD_R2R_PRE_O01) {
+        tab_tw2(p, 4 * nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        s->tile = 4;
+    } else {
+        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        s->tile = 1;
+    }
+}
+
+/* epi: 0 = store the half spectrum as complex numbers; FFTW_AMD_R2R_POST_* = the
+   untangle step applies that r2r epilogue and writes reals of stride cs instead
+   (even lengths only; returns 1 when the epilogue was fused, 0 when the caller
+   still has to run it on the complex result) */
+static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs, fa_loc out, i64 cs, int epi) {
     fa_axis ax = *axp;
     i64 half = nl / 2 + 1;
     int j;
@@ -907,7 +930,7 @@ static void emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs
         s->os_l = cs;
         s->aux_n = nl;
         s->aux_valid = lts[vloop];
-        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        r2r_fuse_tables(p, s, nl, epi);
         nd = 0;
         for (j = 0; j < ax.nloops; ++j) {
             d[nd].n = ax.loops[j].n; d[nd].is = lts[j]; d[nd].os = ax.loops[j].os;
@@ -945,7 +968,7 @@ static void emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs
         s->is_l = zts;
         s->os_l = cs;
         s->aux_n = nl;
-        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        r2r_fuse_tables(p, s, nl, epi);
         nd = 0;
         for (j = 0; j < ax.nloops; ++j) {
             d[nd].n = ax.loops[j].n; d[nd].is = lts[j]; d[nd].os = ax.loops[j].os;
@@ -981,8 +1004,9 @@ static void emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs
         }
         emit_copy(p, FFTW_AMD_STEP_COPY, f, out, half, half, fts, cs, d, nd, 0, -1, -1);
         buf_release(p, fbuf);
+        return 0;
     }
-
+    return epi != 0;
 }
 
 static void build_r2c(plan *p) {
@@ -997,7 +1021,7 @@ static void build_r2c(plan *p) {
     memset(&ax, 0, sizeof(ax));
     if (collect_loops(p, p->dims, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
 
-    emit_r2c_axis(p, nl, &ax, in, p->dims[r - 1].is, out, p->dims[r - 1].os);
+    emit_r2c_axis(p, nl, &ax, in, p->dims[r - 1].is, out, p->dims[r - 1].os, 0);
 
     for (a = r - 2; a >= 0; --a) {
         fa_axis cx;
@@ -1016,7 +1040,10 @@ static void build_r2c(plan *p) {
 /* half spectrum -> real along one axis (unnormalised backward).  ax: the loops
    (.is = strides in the complex source `cur`, .os = strides in the real
    destination); cs / rs: element strides of the transform index, in doubles. */
-static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 cs, fa_loc out, i64 rs) {
+/* pro: 0 = `cur` holds the half spectrum as complex numbers; FFTW_AMD_R2R_PRE_* =
+   `cur` is the user's real r2r input of stride cs and the tangle step applies
+   that prologue while loading (even lengths only, see r2r_can_fuse) */
+static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 cs, fa_loc out, i64 rs, int pro) {
     fa_axis ax = *axp;
     int j;
     if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
@@ -1048,7 +1075,7 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         s->os_l = zts;
         s->aux_n = nl;
         s->aux_valid = lts[vloop];
-        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        r2r_fuse_tables(p, s, nl, pro);
         nd = 0;
         for (j = 0; j < ax.nloops; ++j) {
             d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
@@ -1086,7 +1113,7 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         s->is_l = cs;
         s->os_l = zts;
         s->aux_n = nl;
-        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        r2r_fuse_tables(p, s, nl, pro);
         nd = 0;
         for (j = 0; j < ax.nloops; ++j) {
             d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
@@ -1207,7 +1234,7 @@ static void build_c2r(plan *p) {
         if (collect_loops(&view, td, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
     }
 
-    emit_c2r_axis(p, nl, &ax, cur, cdims[r - 1].is, out, p->dims[r - 1].os);
+    emit_c2r_axis(p, nl, &ax, cur, cdims[r - 1].is, out, p->dims[r - 1].os, 0);
     if (cbuf >= 0) buf_release(p, cbuf);
 }
 
@@ -1266,7 +1293,7 @@ static fftw_amd_step_desc *emit_r2r_step(plan *p, int mode, i64 n, i64 K, i64 tw
 static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc in, i64 rs,
                           fa_loc out, i64 os) {
     enum { IN_R2C, IN_C2R, IN_C2C };
-    int pre = 0, post = 0, inner = IN_R2C, j, nl = axp->nloops;
+    int pre = 0, post = 0, inner = IN_R2C, j, nl = axp->nloops, fuse_pre = 0, fuse_post = 0;
     i64 N = n, cntA = 0, unitA = 1, cntB = 0, unitB = 1, twmod = 0, Kpre = 0, Kpost = 0;
     i64 lis_user[FA_MAXLOOPS], los_user[FA_MAXLOOPS], ltsA[FA_MAXLOOPS], ltsB[FA_MAXLOOPS];
     i64 tsA = 0, tsB = 0;
@@ -1327,6 +1354,11 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
         return;
     }
 
+    /* even inner length: the untangle / tangle step of the real transform does the
+       r2r post / pre processing itself, one pass over the data less */
+    if (inner == IN_R2C && post && r2r_can_fuse(N)) { fuse_post = 1; cntB = 0; }
+    if (inner == IN_C2R && pre && r2r_can_fuse(N)) { fuse_pre = 1; cntA = 0; }
+
     if (cntA) {
         i64 total;
         lay = *axp;
@@ -1345,21 +1377,33 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
         B.buf = bbuf;
     }
 
-    if (pre) emit_r2r_step(p, pre, n, Kpre, twmod, in, rs, A, tsA, axp, lis_user, ltsA, 0);
+    if (pre && !fuse_pre) emit_r2r_step(p, pre, n, Kpre, twmod, in, rs, A, tsA, axp, lis_user, ltsA, 0);
 
     iax = *axp;
     iax.flags_in = iax.flags_out = 0;
     iax.dense = 0;
     if (inner == IN_R2C) {
         fa_loc s = pre ? A : in;
-        for (j = 0; j < nl; ++j) { iax.loops[j].is = pre ? ltsA[j] : lis_user[j]; iax.loops[j].os = ltsB[j]; }
+        for (j = 0; j < nl; ++j) {
+            iax.loops[j].is = pre ? ltsA[j] : lis_user[j];
+            iax.loops[j].os = fuse_post ? los_user[j] : ltsB[j];
+        }
         s.im = 0;
-        emit_r2c_axis(p, N, &iax, s, pre ? tsA : rs, B, tsB);
+        if (fuse_post) {
+            emit_r2c_axis(p, N, &iax, s, pre ? tsA : rs, out, os, post);
+            post = 0;
+        } else {
+            emit_r2c_axis(p, N, &iax, s, pre ? tsA : rs, B, tsB, 0);
+        }
     } else if (inner == IN_C2R) {
         fa_loc d = post ? B : out;
-        for (j = 0; j < nl; ++j) { iax.loops[j].is = ltsA[j]; iax.loops[j].os = post ? ltsB[j] : los_user[j]; }
+        for (j = 0; j < nl; ++j) {
+            iax.loops[j].is = fuse_pre ? lis_user[j] : ltsA[j];
+            iax.loops[j].os = post ? ltsB[j] : los_user[j];
+        }
         d.im = 0;
-        emit_c2r_axis(p, N, &iax, A, tsA, d, post ? tsB : os);
+        if (fuse_pre) emit_c2r_axis(p, N, &iax, in, rs, d, post ? tsB : os, pre);
+        else emit_c2r_axis(p, N, &iax, A, tsA, d, post ? tsB : os, 0);
     } else {
         for (j = 0; j < nl; ++j) { iax.loops[j].is = ltsA[j]; iax.loops[j].os = ltsA[j]; }
         iax.n = N; iax.is = tsA; iax.os = tsA;
@@ -1805,13 +1849,17 @@ char *fa_sprint(const plan *p) {
             }
             len += (size_t)snprintf(s + len, cap - len, " tile=%d", d->tile);
             if (d->tw_n) len += (size_t)snprintf(s + len, cap - len, " tw=%lld", d->tw_n);
-        } else if (d->kind == FFTW_AMD_STEP_R2R) {
+        } else if (d->kind == FFTW_AMD_STEP_R2R ||
+                   ((d->kind == FFTW_AMD_STEP_R2C_POST || d->kind == FFTW_AMD_STEP_R2C_POST4 ||
+                     d->kind == FFTW_AMD_STEP_C2R_PRE || d->kind == FFTW_AMD_STEP_C2R_PRE4) && d->variant)) {
+            /* untangle / tangle steps carry the name of a fused r2r epilogue / prologue */
             static const char *mn[] = { "?", "pre-hc2r", "pre-e10", "pre-o10", "pre-e01", "pre-o01", "pre-e00",
                 "pre-o00", "pre-e11", "pre-o11", "pre-e11odd", "pre-o11odd", "post-r2hc", "post-dht",
                 "post-e10", "post-o10", "post-e01", "post-o01", "post-e00", "post-o00", "post-e11",
                 "post-o11", "post-e11odd", "post-o11odd" };
             int m = (d->variant >= 1 && d->variant <= FFTW_AMD_R2R_POST_O11ODD) ? d->variant : 0;
-            len += (size_t)snprintf(s + len, cap - len, "-%s n=%lld", mn[m], d->aux_n);
+            len += (size_t)snprintf(s + len, cap - len, "%s%s n=%lld", d->kind == FFTW_AMD_STEP_R2R ? "-" : "+r2r-",
+                                    mn[m], d->aux_n);
         } else {
             len += (size_t)snprintf(s + len, cap - len, " n=%lld", d->aux_n);
         }

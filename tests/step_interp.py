@@ -182,7 +182,7 @@ class Interp(object):
                 soff = soff + gi * dis[i]
                 doff = doff + gi * dos[i]
             km = h - k
-            w = self.tw2(s, k)
+            w = self.tw2(s, k * max(1, s.tile))
             if s.kind == fa.STEP_R2C_POST:
                 zk = _load(src, soff + k * s.is_l, s.src_im, 0)
                 zm = _load(src, soff + np.where(km == h, 0, km) * s.is_l, s.src_im, 0)
@@ -194,11 +194,11 @@ class Interp(object):
                 yk = np.where(k == 0, yk.real + 0j, yk)
                 ym = np.where(k == 0, ym.real + 0j, ym)
                 # mirrored element first so that k == h-k keeps Y[k]
-                _store(dst, doff + km * s.os_l, s.dst_im, s.flags, ym)
-                _store(dst, doff + k * s.os_l, s.dst_im, s.flags, yk)
+                self._epi_store(s, dst, doff, km, ym)
+                self._epi_store(s, dst, doff, k, yk)
             else:
-                yk = _load(src, soff + k * s.is_l, s.src_im, 0)
-                ym = _load(src, soff + km * s.is_l, s.src_im, 0)
+                yk = self._pro_load(s, src, soff, k)
+                ym = self._pro_load(s, src, soff, km)
                 yk = np.where(k == 0, yk.real + 0j, yk)
                 ym = np.where(k == 0, ym.real + 0j, ym)
                 E = yk + np.conj(ym)
@@ -222,7 +222,8 @@ class Interp(object):
             for i, gi in enumerate(idx):
                 soff = soff + gi * dis[i]
                 doff = doff + gi * dos[i]
-            w = [None, self.tw2(s, k), self.tw2(s, 2 * k), self.tw2(s, 3 * k)]
+            tm = max(1, s.tile)
+            w = [None, self.tw2(s, k * tm), self.tw2(s, 2 * k * tm), self.tw2(s, 3 * k * tm)]
             if s.kind == fa.STEP_R2C_POST4:
                 km = np.where(k == 0, 0, m - k)
                 T = []
@@ -239,15 +240,15 @@ class Interp(object):
                 y0 = np.where(k == 0, y0.real + 0j, y0)
                 y2 = np.where(k == 0, y2.real + 0j, y2)
                 # duplicates first, the canonical writers last
-                _store(dst, doff + (m - k) * s.os_l, s.dst_im, s.flags, np.where((k == 0), y1, y3))
-                _store(dst, doff + (2 * m - k) * s.os_l, s.dst_im, s.flags, y2)
-                _store(dst, doff + (k + m) * s.os_l, s.dst_im, s.flags, y1)
-                _store(dst, doff + k * s.os_l, s.dst_im, s.flags, y0)
+                self._epi_store(s, dst, doff, m - k, np.where((k == 0), y1, y3))
+                self._epi_store(s, dst, doff, 2 * m - k, y2)
+                self._epi_store(s, dst, doff, k + m, y1)
+                self._epi_store(s, dst, doff, k, y0)
             else:
-                Yk = _load(src, soff + k * s.is_l, s.src_im, 0)
-                Ykm = _load(src, soff + (k + m) * s.is_l, s.src_im, 0)
-                Y2 = _load(src, soff + (2 * m - k) * s.is_l, s.src_im, 0)
-                Y1 = _load(src, soff + (m - k) * s.is_l, s.src_im, 0)
+                Yk = self._pro_load(s, src, soff, k)
+                Ykm = self._pro_load(s, src, soff, k + m)
+                Y2 = self._pro_load(s, src, soff, 2 * m - k)
+                Y1 = self._pro_load(s, src, soff, m - k)
                 Yk = np.where(k == 0, Yk.real + 0j, Yk)
                 Y2 = np.where(k == 0, Y2.real + 0j, Y2)
 
@@ -291,6 +292,77 @@ class Interp(object):
             self._r2r(s, src, dst, dn, dis, dos, sbase, dbase)
         else:
             raise AssertionError("unknown step kind %d" % s.kind)
+
+    def _r2r_len(self, s):
+        N = s.aux_n
+        if s.variant == fa.R2R_POST_E00:
+            return N // 2 + 1
+        if s.variant == fa.R2R_POST_O00:
+            return N // 2 - 1
+        return N
+
+    def _epi_store(self, s, dst, doff, idx, Y):
+        """store of an untangle step, with the fused r2r epilogue when step.variant names one"""
+        mode = s.variant
+        if mode == 0:
+            _store(dst, doff + idx * s.os_l, s.dst_im, s.flags, Y)
+            return
+        n = self._r2r_len(s)
+        shape = np.broadcast(doff, idx, Y).shape
+        doff = np.broadcast_to(doff, shape)
+        idx = np.broadcast_to(idx, shape)
+        Y = np.broadcast_to(Y, shape)
+        mid = (idx > 0) & (2 * idx < n)
+
+        def put(j, v, mask=None):
+            j = np.broadcast_to(j, shape)
+            v = np.broadcast_to(v, shape)
+            if mask is None:
+                dst[doff + j * s.os_l] = v
+            else:
+                dst[(doff + j * s.os_l)[mask]] = v[mask]
+        if mode == fa.R2R_POST_R2HC:
+            put(idx, Y.real)
+            put(n - idx, Y.imag, mid)
+        elif mode == fa.R2R_POST_DHT:
+            put(idx, np.where(mid, Y.real - Y.imag, Y.real))
+            put(n - idx, Y.real + Y.imag, mid)
+        elif mode in (fa.R2R_POST_E10, fa.R2R_POST_O10):
+            v = (Y.real + 1j * np.where(mid, Y.imag, 0.0)) * np.conj(self.tw2(s, idx))
+            if mode == fa.R2R_POST_E10:
+                put(idx, 2 * v.real)
+                put(n - idx, -2 * v.imag, mid)
+            else:
+                put(n - 1 - idx, 2 * v.real)
+                put(idx - 1, -2 * v.imag, mid)
+        elif mode == fa.R2R_POST_E00:
+            put(idx, Y.real)
+        elif mode == fa.R2R_POST_O00:
+            put(idx - 1, -Y.imag, (idx >= 1) & (idx <= n))
+        else:
+            raise AssertionError("bad fused epilogue %d" % mode)
+
+    def _pro_load(self, s, src, soff, idx):
+        """load of a tangle step, with the fused r2r prologue when step.variant names one"""
+        mode = s.variant
+        if mode == 0:
+            return _load(src, soff + idx * s.is_l, s.src_im, 0)
+        n = s.aux_n
+        shape = np.broadcast(soff, idx).shape
+        soff = np.broadcast_to(soff, shape)
+        idx = np.broadcast_to(idx, shape)
+
+        def get(j, mask=None):
+            if mask is None:
+                return src[soff + j * s.is_l]
+            return np.where(mask, src[soff + np.where(mask, j, 0) * s.is_l], 0.0)
+        if mode == fa.R2R_PRE_HC2R:
+            return get(idx) + 1j * get(n - idx, (idx > 0) & (2 * idx < n))
+        if mode == fa.R2R_PRE_E01:
+            return self.tw2(s, idx) * (get(idx) - 1j * get(n - idx, idx > 0))
+        if mode == fa.R2R_PRE_O01:
+            return self.tw2(s, idx) * (get(n - 1 - idx) - 1j * get(idx - 1, idx > 0))
+        raise AssertionError("bad fused prologue %d" % mode)
 
     def _r2r(self, s, src, dst, dn, dis, dos, sbase, dbase):
         """FFTW_AMD_STEP_R2R as specified in include/fftw3_amd.h / DESIGN.md section 9"""

@@ -252,7 +252,7 @@ def test_r2r_print_plan():
     x = np.zeros(64)
     p = fa.plan_r2r_1d(64, x, x, fa.REDFT10)
     s = p.sprint()
-    assert "rdft-r2r" in s and "r2r-pre-e10" in s and "r2r-post-e10" in s
+    assert "rdft-r2r" in s and "r2r-pre-e10" in s and "+r2r-post-e10" in s
 
 
 # ------------------------------------------------------------------ GPU tier
