@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the FFT executor on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2c|r2c|mixed|2d]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2c|r2c|mixed|2d|dct2|dct2-2d]
 
 A "step" is one fftw_execute of the whole batch of synthetic input that is
 already resident in HBM.  At N=1 the default workload is BASELINE.json
@@ -53,6 +53,14 @@ def workload(name, batch_override):
         n = [4096, 4096]
         b = 64            # per-GPU share of 512 images on 8 GPUs
         kind = "c2c"
+    elif name == "dct2":
+        n = [1 << 20]
+        b = 2048
+        kind = "r2r"      # REDFT10 (DCT-II), SURVEY.md 8(f) row 3
+    elif name == "dct2-2d":
+        n = [4096, 4096]
+        b = 32
+        kind = "r2r"
     else:
         raise SystemExit("unknown workload " + name)
     if batch_override:
@@ -63,6 +71,9 @@ def workload(name, batch_override):
     if kind == "c2c":
         flops = 5.0 * size * math.log2(size)
         abytes = 32.0 * size
+    elif kind == "r2r":
+        flops = 2.5 * size * math.log2(size)      # reference libbench2/mflops.c:25-28
+        abytes = 16.0 * size                      # n reals in, n reals out
     else:
         flops = 2.5 * size * math.log2(size)
         abytes = 8.0 * size + 16.0 * (size // n[-1]) * (n[-1] // 2 + 1)
@@ -90,12 +101,15 @@ def pmc_traffic(step, units):
 def cpu_baseline(n, kind, flops_per_transform, target_seconds=12.0):
     """the oracle (a port, one core) on a bounded sample of the same workload"""
     import numpy as np
-    from util import oracle_dft, oracle_r2c
+    from util import oracle_dft, oracle_r2c, oracle_r2r
     rng = np.random.default_rng(1)
     size = int(np.prod(n))
     if kind == "c2c":
         x = (rng.random(size) - 0.5) + 1j * (rng.random(size) - 0.5)
         run = lambda: oracle_dft(x, tuple(n), 1)
+    elif kind == "r2r":
+        x = rng.random(size) - 0.5
+        run = lambda: oracle_r2r(x, list(n), [5] * len(n))
     else:
         x = rng.random(size) - 0.5
         run = lambda: oracle_r2c(x, tuple(n), 1)
@@ -170,6 +184,11 @@ def main():
         y = torch.empty_like(x)
         plan = fa.plan_many_dft(len(n), n, b, x, None, 1, size, y, None, 1, size, fa.FORWARD,
                                 fa.ESTIMATE)
+    elif kind == "r2r":
+        x = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
+        y = torch.empty_like(x)
+        plan = fa.plan_many_r2r(len(n), n, b, x, None, 1, size, y, None, 1, size,
+                                [fa.REDFT10] * len(n), fa.ESTIMATE)
     else:
         hs = size // n[-1] * (n[-1] // 2 + 1)
         x = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
@@ -209,6 +228,8 @@ def main():
         avg_ms = ms / max(1, launches)
         units = min(plan.chunk, plan.batch)           # transforms one launch processes
         # a pass reads every element of its chunk once and writes it once
+        # (r2r: every step of the REDFT10 plan moves n reals in and n reals out per transform,
+        # the half-length complex passes included)
         bytes_per_launch = abytes1 * units
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         roof = {

@@ -539,10 +539,12 @@ __global__ void __launch_bounds__(256) r2r_kernel(const R2RArgs a) {
         }
         case FFTW_AMD_R2R_PRE_E10:
         case FFTW_AMD_R2R_PRE_O10: {
-            i64 si = (k < (n + 1) / 2) ? 2 * k : 2 * n - 1 - 2 * k;
-            double v = SR(si);
-            if (a.mode == FFTW_AMD_R2R_PRE_O10 && (si & 1)) v = -v;
-            DR(k) = v;
+            /* v[j] = x[2j], v[n-1-j] = x[2j+1]: one work item per input pair */
+            DR(k) = SR(2 * k);
+            if (2 * k + 1 < n) {
+                double b = SR(2 * k + 1);
+                DR(n - 1 - k) = (a.mode == FFTW_AMD_R2R_PRE_O10) ? -b : b;
+            }
             break;
         }
         case FFTW_AMD_R2R_PRE_E01:
@@ -618,10 +620,12 @@ __global__ void __launch_bounds__(256) r2r_kernel(const R2RArgs a) {
         }
         case FFTW_AMD_R2R_POST_E01:
         case FFTW_AMD_R2R_POST_O01: {
-            i64 di = (k < (n + 1) / 2) ? 2 * k : 2 * n - 1 - 2 * k;
-            double v = SR(k);
-            if (a.mode == FFTW_AMD_R2R_POST_O01 && (di & 1)) v = -v;
-            DR(di) = v;
+            /* y[2j] = v[j], y[2j+1] = v[n-1-j]: one work item per output pair */
+            DR(2 * k) = SR(k);
+            if (2 * k + 1 < n) {
+                double b = SR(n - 1 - k);
+                DR(2 * k + 1) = (a.mode == FFTW_AMD_R2R_POST_O01) ? -b : b;
+            }
             break;
         }
         case FFTW_AMD_R2R_POST_E00:

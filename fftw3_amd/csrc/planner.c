@@ -1315,13 +1315,13 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
     case FFTW_RODFT10: pre = FFTW_AMD_R2R_PRE_O10; post = FFTW_AMD_R2R_POST_O10;
     makhoul_f:
         inner = IN_R2C; N = n; cntA = n; unitA = 1; cntB = n / 2 + 1; unitB = 2;
-        Kpre = n; Kpost = n / 2 + 1; twmod = 4 * n;
+        Kpre = (n + 1) / 2; Kpost = n / 2 + 1; twmod = 4 * n;
         break;
     case FFTW_REDFT01: pre = FFTW_AMD_R2R_PRE_E01; post = FFTW_AMD_R2R_POST_E01; goto makhoul_b;
     case FFTW_RODFT01: pre = FFTW_AMD_R2R_PRE_O01; post = FFTW_AMD_R2R_POST_O01;
     makhoul_b:
         inner = IN_C2R; N = n; cntA = n / 2 + 1; unitA = 2; cntB = n; unitB = 1;
-        Kpre = n / 2 + 1; Kpost = n; twmod = 4 * n;
+        Kpre = n / 2 + 1; Kpost = (n + 1) / 2; twmod = 4 * n;
         break;
     case FFTW_REDFT00:
         if (n < 2) { p->failed = 1; return; }

@@ -407,11 +407,10 @@ class Interp(object):
             re, im = SR(k), SR(n - k, mid)
             DR(k, re); DI(k, im)
         elif mode in (fa.R2R_PRE_E10, fa.R2R_PRE_O10):
-            si = np.where(k < (n + 1) // 2, 2 * k, 2 * n - 1 - 2 * k)
-            v = SR(si)
-            if mode == fa.R2R_PRE_O10:
-                v = np.where(si & 1, -v, v)
-            DR(k, v)
+            has = 2 * k + 1 < n
+            b = SR(2 * k + 1, has)
+            DR(k, SR(2 * k))
+            DR(n - 1 - k, -b if mode == fa.R2R_PRE_O10 else b, has)
         elif mode in (fa.R2R_PRE_E01, fa.R2R_PRE_O01):
             if mode == fa.R2R_PRE_E01:
                 x, y = SR(k), SR(n - k, k > 0)
@@ -455,11 +454,10 @@ class Interp(object):
                 DR(n - 1 - k, 2 * v.real)
                 DR(k - 1, -2 * v.imag, mid)
         elif mode in (fa.R2R_POST_E01, fa.R2R_POST_O01):
-            di = np.where(k < (n + 1) // 2, 2 * k, 2 * n - 1 - 2 * k)
-            v = SR(k)
-            if mode == fa.R2R_POST_O01:
-                v = np.where(di & 1, -v, v)
-            DR(di, v)
+            has = 2 * k + 1 < n
+            b = SR(n - 1 - k, has)
+            DR(2 * k, SR(k))
+            DR(2 * k + 1, -b if mode == fa.R2R_POST_O01 else b, has)
         elif mode == fa.R2R_POST_E00:
             DR(k, SR(k))
         elif mode == fa.R2R_POST_O00:
