@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the FFT executor on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2c|r2c|mixed|2d|dct2|dct2-2d]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2c|r2c|mixed|2d|dct2|dct2-2d|slab2d]
 
 A "step" is one fftw_execute of the whole batch of synthetic input that is
 already resident in HBM.  At N=1 the default workload is BASELINE.json
@@ -132,6 +132,63 @@ def cpu_baseline(n, kind, flops_per_transform, target_seconds=12.0):
     }
 
 
+def run_slab(args, torch, fa, dist, world, rank, dev):
+    """--workload slab2d: ONE 16384 x 16384 complex transform distributed in slabs over the
+    ranks (fftw3_amd.slab): strong scaling, two all-to-all exchanges
+    per transform (normal in, normal out)."""
+    from fftw3_amd import slab
+    n0 = n1 = args.batch or 16384
+    alloc, ln0, s0, ln1, s1 = slab.local_size_2d_transposed(n0, n1, world, rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)
+    x = torch.view_as_complex(torch.rand((max(1, alloc), 2), dtype=torch.float64, device=dev, generator=gen) - 0.5)
+    y = torch.empty_like(x)
+    plan = slab.plan_dft_2d(n0, n1, x, y, fa.FORWARD, fa.ESTIMATE, world=world, rank=rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        plan.execute()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.execute()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    # time of the exchanges alone (same buffers, same splits)
+    ex = [p for k, p in plan.stages if k == "a2a"]
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for e in ex:
+            e.run()
+    barrier()
+    dte = time.perf_counter() - t0
+    size = n0 * n1
+    flops = 5.0 * size * math.log2(size)
+    if rank == 0:
+        sent = sum(sum(e.send_counts) - e.send_counts[rank] for e in ex) * 16
+        print(json.dumps({
+            "metric": "GFLOPS (5N*log2N), one 2D complex double transform %dx%d in slabs over the GPUs" % (n0, n1),
+            "value": flops * args.steps / dt / 1e9, "unit": "GFLOPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "slab2d %dx%d c2c forward, normal in / normal out" % (n0, n1),
+                       "local_plans": plan.num_local_plans(), "exchanges": plan.num_exchanges(),
+                       "parallelism": "slab x%d" % world},
+            "exchange": {"ms_per_step": dte / args.steps * 1e3, "bytes_sent_per_rank_per_step": sent,
+                         "GBs_per_rank": sent * args.steps / dte / 1e9 if dte > 0 else None},
+        }))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +218,9 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     if fa.device_count() <= 0:
         raise SystemExit("bench.py needs a HIP device: the executor has no CPU path")
+
+    if args.workload == "slab2d":
+        return run_slab(args, torch, fa, dist, world, rank, dev)
 
     n, b, kind, flops1, abytes1 = workload(args.workload, args.batch)
     size = 1

@@ -59,6 +59,86 @@ def test_shard_range_is_a_partition():
             assert max(sizes) == (batch + world - 1) // world          # block rule of mpi/block.c:35-42
 
 
+def _run_ranks(script, world, timeout=300):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, FA_ROOT=ROOT, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out)
+        assert "rank %d ok" % rank in out
+
+
+def test_slab_local_size_matches_reference_block_rule():
+    """fftw_mpi_local_size_*: blocks of ceil(n/P), trailing ranks may be empty (mpi/block.c:39-50)"""
+    from fftw3_amd import slab
+    for n0, n1, world in [(8, 6, 2), (7, 9, 3), (5, 4, 8), (4096, 4096, 8), (3, 32, 4)]:
+        rows = cols = 0
+        for r in range(world):
+            alloc, ln0, s0, ln1, s1 = slab.local_size_2d_transposed(n0, n1, world, r)
+            assert s0 == min(n0, r * ((n0 + world - 1) // world)) and s1 == min(n1, r * ((n1 + world - 1) // world))
+            assert alloc == max(ln0 * n1, ln1 * n0)
+            rows += ln0
+            cols += ln1
+        assert rows == n0 and cols == n1
+    a, ln0, s0 = slab.local_size_3d(10, 6, 4, 4, 3)
+    assert (ln0, s0) == (1, 9) and a == max(1 * 6, 0 * 10) * 4
+
+
+def test_slab_world1_without_process_group():
+    """world = 1: the exchange degenerates to a copy; every kind against the oracle"""
+    import torch
+    from fftw3_amd import slab
+    from step_interp import run_plan_on_host
+    from util import oracle_dft, oracle_r2r, aerror, TOL
+
+    def host_exec(plan, src, dst):
+        run_plan_on_host(plan, src.numpy(), dst.numpy())
+    rng = np.random.default_rng(2)
+    n = [6, 10, 4]
+    full = (rng.random(n) - 0.5) + 1j * (rng.random(n) - 0.5)
+    x = torch.from_numpy(full.reshape(-1).copy())
+    y = torch.zeros_like(x)
+    p = slab.plan_dft_3d(6, 10, 4, x, y, fa_sign_forward(), executor=host_exec, world=1, rank=0)
+    p.execute()
+    assert p.num_exchanges() == 2
+    assert aerror(y.numpy(), oracle_dft(full.reshape(-1), tuple(n), 1)) < TOL
+    xr = torch.from_numpy((rng.random(60) - 0.5))
+    yr = torch.zeros_like(xr)
+    q = slab.plan_r2r_2d(6, 10, xr, yr, 5, 7, slab.TRANSPOSED_OUT | 64, executor=host_exec, world=1, rank=0)
+    q.execute()
+    assert q.num_exchanges() == 1
+    want = oracle_r2r(xr.numpy(), [6, 10], [5, 7]).reshape(6, 10).T
+    assert aerror(yr.numpy(), want.reshape(-1)) < TOL
+
+
+def fa_sign_forward():
+    import fftw3_amd as fa
+    return fa.FORWARD
+
+
+def test_two_rank_gloo_slab_transforms():
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "slab_worker.py"), 2)
+
+
+def test_three_rank_gloo_slab_transforms_uneven_blocks():
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "slab_worker.py"), 3)
+
+
 def test_two_rank_gloo_sharded_transform_and_gather(tmp_path):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
