@@ -148,11 +148,12 @@ static plan *finish(plan *p, double *ri, double *ii, double *ro, double *io) {
             static const size_t chunks[] = { (size_t)256 << 20, (size_t)1 << 30, (size_t)4 << 30 };
             fa_cfg best = p->cfg, c;
             double best_ms = -1.0;
-            int ci, pi, li, st, nl = (p->flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1;
+            int ci, pi, li, st, lf, nl = (p->flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1;
             for (ci = 0; ci < 3; ++ci)
                 for (pi = 0; pi < 2; ++pi)
                     for (li = 0; li < nl; ++li)
-                        for (st = 0; st < nl; ++st) {
+                        for (st = 0; st < nl; ++st)
+                        for (lf = 0; lf < 2; ++lf) {
                             plan *q;
                             double t0, dt;
                             c = p->cfg;
@@ -160,6 +161,7 @@ static plan *finish(plan *p, double *ri, double *ii, double *ro, double *io) {
                             c.pipeline = pi;
                             c.lmax_multi = li ? 512 : 1024;
                             c.small_tiles = st;
+                            c.long_first = lf;
                             q = clone_problem(p, c);
                             if (!q || fa_build(q)) { fa_plan_free(q); continue; }
                             q->ri = ri; q->ii = ii; q->ro = ro; q->io = io;
@@ -639,7 +641,8 @@ int  fftw_init_threads(void) { return 1; }
 void fftw_cleanup_threads(void) {}
 void fftw_make_planner_thread_safe(void) {}
 
-/* ---- wisdom: text records "(key) chunk pipeline lmax small ms", one per problem */
+/* ---- wisdom: text records "(key) chunk pipeline lmax bits ms", one per problem
+   (bits: 1 = small_tiles, 2 = long_first) */
 void fftw_forget_wisdom(void) {
     while (g_wisdom) { wis_entry *n = g_wisdom->next; free(g_wisdom); g_wisdom = n; }
 }
@@ -655,7 +658,7 @@ char *fftw_export_wisdom_to_string(void) {
     len += (size_t)snprintf(s + len, cap - len, "(fftw3_amd_wisdom-1\n");
     for (w = g_wisdom; w; w = w->next)
         len += (size_t)snprintf(s + len, cap - len, "  (%s) %zu %d %d %d %.6f\n", w->key, w->cfg.chunk_bytes,
-                                w->cfg.pipeline, w->cfg.lmax_multi, w->cfg.small_tiles, w->ms);
+                                w->cfg.pipeline, w->cfg.lmax_multi, (w->cfg.small_tiles ? 1 : 0) | (w->cfg.long_first ? 2 : 0), w->ms);
     snprintf(s + len, cap - len, ")\n");
     return s;
 }
@@ -702,7 +705,7 @@ int fftw_import_wisdom_from_string(const char *input) {
         w = (wis_entry *)calloc(1, sizeof(*w));
         if (!w) { ok = 0; break; }
         snprintf(w->key, sizeof(w->key), "%s", key);
-        w->cfg.chunk_bytes = chunk; w->cfg.pipeline = pipe != 0; w->cfg.lmax_multi = lmax; w->cfg.small_tiles = small != 0;
+        w->cfg.chunk_bytes = chunk; w->cfg.pipeline = pipe != 0; w->cfg.lmax_multi = lmax; w->cfg.small_tiles = (small & 1) != 0; w->cfg.long_first = (small & 2) != 0;
         w->ms = ms;
         w->next = staged;
         staged = w;

@@ -61,6 +61,7 @@ typedef struct {
     int pipeline;         /* two-stream chunk pipeline on/off */
     int lmax_multi;       /* longest sub-transform of a multi-pass split */
     int small_tiles;      /* half-size tiles in the generic LDS kernel */
+    int long_first;       /* multi-pass splits run the longest sub-transform first */
 } fa_cfg;
 
 typedef struct {

@@ -56,7 +56,23 @@ template <int R, int D, bool HAVE, bool PERM> struct TwTreeR<R, -1, D, HAVE, PER
 
 /* sequences per tile: as many as fit 8192 elements while an item keeps at most
    ~34 (stage 1) / ~40 (stage 2) elements in registers */
+#ifndef FA_RR_SMALL_ELEMS
+#define FA_RR_SMALL_ELEMS 4096
+#endif
+#ifndef FA_RR_SMALL_MAXL
+#define FA_RR_SMALL_MAXL 256
+#endif
+#ifndef FA_RR_SMALL_WGS
+#define FA_RR_SMALL_WGS 4
+#endif
+/* powers of two without a radix-32 stage run 16 elements per item (tile of 4096):
+   with 32 the butterflies' temporaries push the 256-VGPR budget into scratch
+   (measured: 60-120 spilled VGPRs, passes at ~2 TB/s instead of ~5) */
+constexpr bool fa_rr_small(int R1, int R2) {
+    return ((R1 & (R1 - 1)) == 0) && ((R2 & (R2 - 1)) == 0) && R1 * R2 <= FA_RR_SMALL_MAXL;
+}
 constexpr int fa_rr_tile(int R1, int R2) {
+    if (fa_rr_small(R1, R2)) return FA_RR_SMALL_ELEMS / (R1 * R2);
     int T = 8192 / (R1 * R2);
     /* powers of two run with exactly 32 elements per item; the odd-prime butterflies
        need more temporaries, so their items keep at most 30 / 28 elements (measured:
@@ -114,7 +130,7 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
 #pragma unroll
     for (int u = 0; u < Q1; ++u) {
         const int g = u * 256 + tid;
-        ok1[u] = g < G::NB1;                         /* the last butterfly slot may be empty */
+        ok1[u] = (G::NB1 % 256 == 0) || g < G::NB1;  /* the last butterfly slot may be empty */
         t1[u] = IN_T ? (g % T) : (g / R2);
         a1[u] = IN_T ? (g / T) : (g % R2);
         const double *p = a.src + (i64)a1[u] * a.is_l + FA_TILE_SOFF(a, t1[u]);
@@ -160,7 +176,7 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
 #pragma unroll
     for (int v = 0; v < Q2; ++v) {
         const int h = v * 256 + tid;
-        ok2[v] = h < G::NB2;
+        ok2[v] = (G::NB2 % 256 == 0) || h < G::NB2;
         t2[v] = OUT_T ? (h % T) : (h / R1);
         d2[v] = OUT_T ? (h / T) : (h % R1);
     }
@@ -216,7 +232,7 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
 
 /* kernel arguments are those of pass1024 (P1024Args): same dims / strides / tables */
 template <int R1, int R2, bool IN_T, bool OUT_T, int HAS_TW>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, fa_rr_small(R1, R2) ? FA_RR_SMALL_WGS : 2)
 passrr_kernel(const P1024Args a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
     constexpr int T = RRGeom<R1, R2>::T;

@@ -27,6 +27,7 @@ static size_t g_chunk_bytes = (size_t)1 << 30;
 static i64 g_lmax_multi = 1024;
 static int g_pipeline = 1;
 static int g_small_tiles = 1;
+static int g_long_first = 0;
 static int g_mixed = 0, g_mixed_chunk = 4;
 static int g_fused = 0, g_fused_lag = 5, g_fused_slots = 10;   /* opt-in: FFTW_AMD_FUSED=1 */
 
@@ -40,6 +41,7 @@ fa_cfg fa_default_cfg(void) {
     c.pipeline = g_pipeline;
     c.lmax_multi = (int)g_lmax_multi;
     c.small_tiles = g_small_tiles;
+    c.long_first = g_long_first;
     return c;
 }
 
@@ -65,6 +67,8 @@ plan *fa_plan_new(void) {
     if (e && atoi(e) >= 1) g_fused_lag = atoi(e);
     e = getenv("FFTW_AMD_SMALL_TILES");
     if (e) g_small_tiles = atoi(e);
+    e = getenv("FFTW_AMD_LONG_FIRST");
+    if (e) g_long_first = atoi(e);
     e = getenv("FFTW_AMD_PIPELINE");
     if (e) g_pipeline = atoi(e);
     e = getenv("FFTW_AMD_LMAX_MULTI");
@@ -759,6 +763,13 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
         return;
     }
     if (ax.nloops + k > FFTW_AMD_MAX_DIMS) { p->failed = 1; return; }
+    if (p->cfg.long_first) {
+        /* longest sub-transform first (FFTW_MEASURE candidate) */
+        int a, b;
+        for (a = 0; a < k; ++a)
+            for (b = a + 1; b < k; ++b)
+                if (lens[b] > lens[a]) { i64 t = lens[a]; lens[a] = lens[b]; lens[b] = t; }
+    }
     emit_ct(p, &ax, lens, k);
 }
 
