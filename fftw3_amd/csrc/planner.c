@@ -473,16 +473,17 @@ static int loops_to_sdims(const fa_axis *ax, sdim *d, int use_dst_as_src) {
 static i64 scratch_layout_u(const fa_axis *ax, i64 n_axis, i64 unit, i64 *ts_axis, i64 *ts_loop) {
     int order[FA_MAXLOOPS + 1], cnt = 0, i, j;
     i64 key[FA_MAXLOOPS + 1], stride = unit;
-    /* index -1 denotes the axis itself */
+    /* index -1 denotes the axis itself; it comes first so that it wins ties (callers pass
+       is = 1 to ask for the axis innermost, and a loop of real data may have stride 1 too) */
+    order[cnt] = -1;
+    key[cnt] = iabs(ax->is);
+    ++cnt;
     for (i = 0; i < ax->nloops; ++i) {
         if (i == ax->batch_loop) continue;
         order[cnt] = i;
         key[cnt] = iabs(ax->loops[i].is);
         ++cnt;
     }
-    order[cnt] = -1;
-    key[cnt] = iabs(ax->is);
-    ++cnt;
     /* insertion sort ascending by source stride: smallest stride innermost */
     for (i = 1; i < cnt; ++i) {
         int o = order[i];

@@ -321,3 +321,22 @@ def test_planner_random_composite_shapes():
         run_plan_on_host(p, x, y)
         ref = oracle_dft(x, shape, v, sign, istride=istride, idist=idist, ostride=istride, odist=idist)
         assert aerror(y.reshape(-1), ref) < TOL, (case, shape, v, vtype, sign, p.sprint())
+
+
+def test_guru_r2c_column_major_real_input_with_rader_half_length():
+    """regression: a non-batch loop of stride 1 (real data) around a Rader sub-transform -- the
+    scratch layout must still put the transform axis innermost (the rader-mul step walks
+    contiguous vectors)"""
+    import fftw3_amd as fa
+    from step_interp import run_plan_on_host
+    from util import oracle_r2c, rrand
+    rng = np.random.default_rng(31)
+    n0, n1 = 3, 106                      # half length 53: prime, Rader over 52
+    nh = n1 // 2 + 1
+    xt = rrand(rng, n1, n0)              # memory [n1][n0]: x[i0][i1] = xt[i1][i0]
+    x = xt.reshape(-1).copy()
+    y = np.zeros(n0 * nh, dtype=np.complex128)
+    p = fa.plan_guru64_dft_r2c([(n0, 1, nh), (n1, n0, 1)], [], x, y)
+    assert "rader-mul" in p.sprint()
+    run_plan_on_host(p, x, y)
+    assert aerror(y, oracle_r2c(np.ascontiguousarray(xt.T).reshape(-1), [n0, n1], 1)) < TOL

@@ -255,6 +255,58 @@ def test_r2r_print_plan():
     assert "rdft-r2r" in s and "r2r-pre-e10" in s and "+r2r-post-e10" in s
 
 
+def _random_r2r_cases(seed, count, budget_total):
+    """the reference's random sweep (fftw/tests/check.pl:186-251) restricted to r2r problems:
+    random rank <= 3, dims from factors <= 13 (plus the odd prime), a random kind per dim,
+    vector none / contiguous / interleaved, in or out of place"""
+    rng = np.random.default_rng(seed)
+    primes = [2, 3, 5, 7, 11, 13]
+    for case in range(count):
+        rank = int(rng.integers(1, 4))
+        shape, kinds = [], []
+        budget = budget_total ** (1.0 / rank)
+        for _ in range(rank):
+            n = 1
+            while True:
+                f = primes[int(rng.integers(0, len(primes)))]
+                if n * f > max(2.0, budget):
+                    break
+                n *= f
+                if rng.random() < 0.25:
+                    break
+            if rng.random() < 0.15:
+                n = [17, 31, 37, 97, 101][int(rng.integers(0, 5))]     # generic / Rader / Bluestein inside r2r
+            k = int(rng.integers(0, 11))
+            if k == fa.REDFT00 and n < 2:
+                n = 2
+            shape.append(n)
+            kinds.append(k)
+        vtype = int(rng.integers(0, 3))
+        v = 1 if vtype == 0 else int(rng.integers(2, 5))
+        inplace = bool(rng.random() < 0.5)
+        nn = int(np.prod(shape))
+        if vtype == 2:
+            x = rrand(rng, *(tuple(shape) + (v,)))
+            stride, dist = v, 1
+        else:
+            x = rrand(rng, *((v,) + tuple(shape)))
+            stride, dist = 1, nn
+        yield case, shape, kinds, v, stride, dist, inplace, x
+
+
+def test_planner_r2r_random_sweep():
+    for case, shape, kinds, v, stride, dist, inplace, x in _random_r2r_cases(4321, 60, 20000):
+        xin = x.reshape(-1).copy()
+        y = xin if inplace else np.zeros_like(xin)
+        p = fa.plan_many_r2r(len(shape), shape, v, xin, None, stride, dist, y, None, stride, dist, kinds)
+        run_plan_on_host(p, xin, y)
+        want = np.zeros(x.size)
+        oracle_r2r(x.reshape(-1), shape, kinds, howmany=v, out=want, istride=stride, idist=dist,
+                   ostride=stride, odist=dist)
+        e = aerror(y, want)
+        assert e <= TOL, (case, shape, [NAMES[k] for k in kinds], v, stride, inplace, e, p.sprint())
+
+
 # ------------------------------------------------------------------ GPU tier
 
 def _dev(a):
@@ -334,6 +386,44 @@ def test_gpu_r2r_strided_inplace_newarray():
         p.sync()
         assert aerror(da.cpu().numpy(), oracle_r2r(a, [n], [kind], howmany=hm)) <= TOL
         assert aerror(db.cpu().numpy(), oracle_r2r(b, [n], [kind], howmany=hm)) <= TOL
+
+
+@pytest.mark.gpu
+def test_gpu_r2r_random_sweep():
+    import torch
+    for case, shape, kinds, v, stride, dist, inplace, x in _random_r2r_cases(987, 80, 200000):
+        dx = _dev(x.reshape(-1))
+        dy = dx if inplace else torch.zeros_like(dx)
+        p = fa.plan_many_r2r(len(shape), shape, v, dx, None, stride, dist, dy, None, stride, dist, kinds)
+        p.execute()
+        p.sync()
+        want = np.zeros(x.size)
+        oracle_r2r(x.reshape(-1), shape, kinds, howmany=v, out=want, istride=stride, idist=dist,
+                   ostride=stride, odist=dist)
+        e = aerror(dy.cpu().numpy(), want)
+        assert e <= TOL, (case, shape, [NAMES[k] for k in kinds], v, stride, inplace, e, p.sprint())
+
+
+@pytest.mark.gpu
+def test_gpu_r2r_is_capturable_in_a_hip_graph():
+    import torch
+    rng = np.random.default_rng(21)
+    n, b = 4096, 64
+    x0, x1 = rrand(rng, b * n), rrand(rng, b * n)
+    xd = _dev(x0)
+    yd = torch.zeros_like(xd)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        p = fa.plan_many_r2r(1, [n], b, xd, None, 1, n, yd, None, 1, n, [fa.REDFT10])
+        p.execute()                       # warm-up: tables and scratch exist before capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            p.execute()
+    xd.copy_(torch.from_numpy(x1))
+    g.replay()
+    torch.cuda.synchronize()
+    assert aerror(yd.cpu().numpy(), oracle_r2r(x1, [n], [fa.REDFT10], howmany=b)) <= TOL
 
 
 @pytest.mark.gpu
