@@ -211,8 +211,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # FFTW_AMD_BENCH_REHEARSE=1: rehearsal of the multi-rank path on a box with fewer GPUs
+        # than ranks (ranks share cuda:0, gloo in the place of RCCL); never used for numbers
+        rehearse = os.environ.get("FFTW_AMD_BENCH_REHEARSE") == "1"
+        if rehearse:
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)

@@ -80,3 +80,16 @@ def test_slab_gpu_large_2d_equals_single_plan():
     p.sync()
     err = (y - z).abs().max().item() / z.abs().max().item()
     assert err <= TOL
+
+
+def test_slab_gpu_two_ranks_share_the_gpu_gloo_exchange():
+    """two processes, both on cuda:0, gloo all-to-all on device tensors: the multi-rank pipeline
+    (uneven blocks, all kinds, TRANSPOSED flags) with every local plan on the HIP path"""
+    import os
+    from test_distributed import _run_ranks
+    from util import ROOT
+    os.environ["FA_SLAB_DEVICE"] = "cuda"
+    try:
+        _run_ranks(os.path.join(ROOT, "tests", "workers", "slab_worker.py"), 2, timeout=600)
+    finally:
+        del os.environ["FA_SLAB_DEVICE"]
