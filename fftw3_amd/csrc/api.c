@@ -5,6 +5,7 @@
  * layer (fftw/fftw_api.c:1-1516); citations per function.  Errors are
  * reported the FFTW way: planners return NULL, internal failures abort().
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -105,7 +106,7 @@ static void span_of(const fa_dim *d, int nd, int use_os, i64 *lo, i64 *hi) {
     }
 }
 
-static plan *finish(plan *p, double *ri, double *ii, double *ro, double *io) {
+static plan *finish_locked(plan *p, double *ri, double *ii, double *ro, double *io) {
     i64 cnt = 1;
     int i;
     p->ri = ri; p->ii = ii; p->ro = ro; p->io = io;
@@ -186,6 +187,20 @@ static plan *finish(plan *p, double *ri, double *ii, double *ro, double *io) {
        fftw_execute itself allocates nothing (stream capture, latency) */
     if (fa_hip_device_count() > 0 && p->batch > 0 && fa_device_init(p)) { fa_plan_free(p); return NULL; }
     return p;
+}
+
+/* The reference's planner is not reentrant unless fftw_make_planner_thread_safe() was
+   called (fftw/fftw_api.c:14517-14540, threads hook); here the planner's shared state is
+   the wisdom list and the device bring-up, and one lock around them is cheap enough to
+   take always.  Executing different plans from different threads needs no lock at all. */
+static pthread_mutex_t g_planner_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static plan *finish(plan *p, double *ri, double *ii, double *ro, double *io) {
+    plan *r;
+    pthread_mutex_lock(&g_planner_lock);
+    r = finish_locked(p, ri, ii, ro, io);
+    pthread_mutex_unlock(&g_planner_lock);
+    return r;
 }
 
 /* in-place transforms must map every element onto itself
@@ -644,7 +659,9 @@ void fftw_make_planner_thread_safe(void) {}
 /* ---- wisdom: text records "(key) chunk pipeline lmax bits ms", one per problem
    (bits: 1 = small_tiles, 2 = long_first) */
 void fftw_forget_wisdom(void) {
+    pthread_mutex_lock(&g_planner_lock);
     while (g_wisdom) { wis_entry *n = g_wisdom->next; free(g_wisdom); g_wisdom = n; }
+    pthread_mutex_unlock(&g_planner_lock);
 }
 void fftw_cleanup(void) { fftw_forget_wisdom(); }   /* plans stay valid, like the reference (A.c:411-418) */
 
@@ -652,14 +669,16 @@ char *fftw_export_wisdom_to_string(void) {
     size_t cap = 64, len = 0;
     wis_entry *w;
     char *s;
+    pthread_mutex_lock(&g_planner_lock);
     for (w = g_wisdom; w; w = w->next) cap += strlen(w->key) + 96;
     s = (char *)malloc(cap);
-    if (!s) return NULL;
+    if (!s) { pthread_mutex_unlock(&g_planner_lock); return NULL; }
     len += (size_t)snprintf(s + len, cap - len, "(fftw3_amd_wisdom-1\n");
     for (w = g_wisdom; w; w = w->next)
         len += (size_t)snprintf(s + len, cap - len, "  (%s) %zu %d %d %d %.6f\n", w->key, w->cfg.chunk_bytes,
                                 w->cfg.pipeline, w->cfg.lmax_multi, (w->cfg.small_tiles ? 1 : 0) | (w->cfg.long_first ? 2 : 0), w->ms);
     snprintf(s + len, cap - len, ")\n");
+    pthread_mutex_unlock(&g_planner_lock);
     return s;
 }
 void fftw_export_wisdom_to_file(FILE *f) {
@@ -711,12 +730,14 @@ int fftw_import_wisdom_from_string(const char *input) {
         staged = w;
         c = e + 1 + n;
     }
+    pthread_mutex_lock(&g_planner_lock);
     while (staged) {
         w = staged;
         staged = staged->next;
         if (ok) wis_put(w->key, w->cfg, w->ms);
         free(w);
     }
+    pthread_mutex_unlock(&g_planner_lock);
     return ok;
 }
 int fftw_import_wisdom_from_file(FILE *f) {

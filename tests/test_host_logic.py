@@ -340,3 +340,30 @@ def test_guru_r2c_column_major_real_input_with_rader_half_length():
     assert "rader-mul" in p.sprint()
     run_plan_on_host(p, x, y)
     assert aerror(y, oracle_r2c(np.ascontiguousarray(xt.T).reshape(-1), [n0, n1], 1)) < TOL
+
+
+def test_planning_from_many_threads():
+    """ctypes drops the GIL: planner calls really run concurrently; plans must equal the serial ones"""
+    import threading
+    import fftw3_amd as fa
+    sizes = [64, 1000, 4096, 10007, 1 << 16, 15015, 53 * 2, 360]
+    x = np.zeros(1 << 17, dtype=np.complex128)
+    serial = {n: fa.plan_dft_1d(n, x, x, fa.FORWARD).sprint() for n in sizes}
+    errs = []
+
+    def work(seed):
+        rng = np.random.default_rng(seed)
+        for _ in range(40):
+            n = sizes[int(rng.integers(0, len(sizes)))]
+            try:
+                if fa.plan_dft_1d(n, x, x, fa.FORWARD).sprint() != serial[n]:
+                    errs.append(n)
+                fa.import_wisdom_from_string(fa.export_wisdom_to_string())
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[:5]
