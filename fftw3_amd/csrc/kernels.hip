@@ -946,7 +946,9 @@ static int g_lds_attr_done = 0;
 
 template <bool VIN, bool VOUT>
 static void launch_pass_variant(const PassArgs &pa, dim3 grid, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((pass_generic_kernel<VIN, VOUT>), grid, dim3(256), lds, st, pa);
+    static int nth = 0;
+    if (!nth) { const char *e = getenv("FFTW_AMD_GENERIC_THREADS"); nth = e ? atoi(e) : 256; if (nth < 64 || nth > 256) nth = 256; }
+    hipLaunchKernelGGL((pass_generic_kernel<VIN, VOUT>), grid, dim3(nth), lds, st, pa);
 }
 
 /* kernels_rr.hip */

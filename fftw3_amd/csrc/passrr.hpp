@@ -84,6 +84,12 @@ constexpr int fa_rr_tile(int R1, int R2) {
     return T;
 }
 
+/* workgroups per CU the register budget is compiled for: 4 for the 16-element tiles,
+   3 when the tile is small enough that three images fit the LDS (105 = 15 x 7), else 2 */
+constexpr int fa_rr_wgs(int R1, int R2) {
+    return fa_rr_small(R1, R2) ? FA_RR_SMALL_WGS : (R1 * R2 * fa_rr_tile(R1, R2) <= 4096 ? 3 : 2);
+}
+
 template <int R1, int R2> struct RRGeom {
     static constexpr int L = R1 * R2;
     static constexpr int T = fa_rr_tile(R1, R2);
@@ -232,7 +238,7 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
 
 /* kernel arguments are those of pass1024 (P1024Args): same dims / strides / tables */
 template <int R1, int R2, bool IN_T, bool OUT_T, int HAS_TW>
-__global__ void __launch_bounds__(256, fa_rr_small(R1, R2) ? FA_RR_SMALL_WGS : 2)
+__global__ void __launch_bounds__(256, fa_rr_wgs(R1, R2))
 passrr_kernel(const P1024Args a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
     constexpr int T = RRGeom<R1, R2>::T;

@@ -1,18 +1,17 @@
-"""perf exploration: a sweep of sizes (power-of-two and mixed radix), batch ~1 GiB per array"""
-import sys, os, time, math
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+"""exploration: throughput of sizes without a register kernel (not a test)"""
+import time, torch
 import fftw3_amd as fa
-dev = torch.device("cuda:0")
-sizes = [int(v) for v in os.environ.get("SIZES", "1000,5000,15015,60060,59049,78125,1000000,1024,16384,65536,262144,1048576,4194304").split(",")]
-for n in sizes:
-    b = max(1, (1 << 30) // (16 * n))
-    x = torch.randn(b, n, dtype=torch.complex128, device=dev); y = torch.empty_like(x)
-    p = fa.plan_many_dft(1, [n], b, x, None, 1, n, y, None, 1, n, -1)
-    p.execute(); torch.cuda.synchronize()
-    best = 1e9
-    for it in range(3):
-        torch.cuda.synchronize(); t = time.perf_counter(); p.execute(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
-    print("n=%8d b=%7d: %8.3f ms  %6.0f GFLOPS  %5.1f%% of roofline  %s" % (n, b, best * 1e3, 5 * n * math.log2(n) * b / best / 1e9,
-          32 * n * b / best / 8e12 * 100, " ".join(l.strip() for l in p.sprint().split("\n")[1:])[:110]), flush=True)
+for n in (1000, 1536, 1920, 3000, 5000, 10000, 60060, 100000, 5 ** 8):
+    hm = max(1, (1 << 29) // (16 * n) * 2)          # ~1 GiB of input
+    x = torch.view_as_complex(torch.rand((hm * n, 2), dtype=torch.float64, device="cuda") - 0.5)
+    y = torch.zeros_like(x)
+    p = fa.plan_many_dft(1, [n], hm, x, None, 1, n, y, None, 1, n, fa.FORWARD)
+    for _ in range(2): p.execute()
+    p.sync()
+    t0 = time.perf_counter()
+    for _ in range(5): p.execute()
+    p.sync()
+    dt = (time.perf_counter() - t0) / 5
+    gb = 32.0 * n * hm / 1e9
+    print("n=%-8d x%-7d %7.3f ms  %6.0f GB/s alg (%4.1f%% of 8 TB/s)  %s" % (n, hm, dt * 1e3, gb / dt, gb / dt / 80, p.sprint().replace("\n", " ")[:200]), flush=True)
     del x, y, p
