@@ -16,7 +16,7 @@ all: $(LIBDIR)/libfftw3_amd.so
 $(CSRC)/%.o: $(CSRC)/%.c $(CSRC)/fa_plan.h $(CSRC)/fa_hip.h include/fftw3.h include/fftw3_amd.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_amd.h $(wildcard $(CSRC)/*.hpp)
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_amd.h $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libfftw3_amd.so: $(OBJS)

@@ -257,4 +257,103 @@ template <> struct Bfly<15> {
     }
 };
 
+/* ---- composite radices ---------------------------------------------------- */
+/* Coprime factors: the prime-factor (Good-Thomas) map needs no twiddles, only
+   compile-time index permutations:  j = (j1 B + j2 A) mod N on the input,
+   k = (k1 e1 + k2 e2) mod N on the output with e1 = B (B^-1 mod A), e2 = A (A^-1 mod B)
+   (the reference's generator makes the same choice for coprime sizes,
+   fftw/genfft/fft.ml:283-300 "prime factor"). */
+constexpr int fa_modinv(int a, int m) {
+    int r = 1;
+    for (int i = 1; i < m; ++i) if ((a * i) % m == 1) r = i;
+    return r;
+}
+template <int A, int B> struct BflyPFA {
+    static constexpr int N = A * B;
+    static constexpr int E1 = B * fa_modinv(B % A, A);
+    static constexpr int E2 = A * fa_modinv(A % B, B);
+    static FA_DEV void run(cplx *x) {
+        cplx z[A][B];
+#pragma unroll
+        for (int j1 = 0; j1 < A; ++j1) {
+#pragma unroll
+            for (int j2 = 0; j2 < B; ++j2) z[j1][j2] = x[(j1 * B + j2 * A) % N];
+            Bfly<B>::run(z[j1]);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) {
+            cplx c[A];
+#pragma unroll
+            for (int j1 = 0; j1 < A; ++j1) c[j1] = z[j1][k2];
+            Bfly<A>::run(c);
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) x[(k1 * E1 + k2 * E2) % N] = c[k1];
+        }
+    }
+};
+template <> struct Bfly<6> : BflyPFA<2, 3> {};
+template <> struct Bfly<10> : BflyPFA<2, 5> {};
+template <> struct Bfly<12> : BflyPFA<4, 3> {};
+template <> struct Bfly<14> : BflyPFA<2, 7> {};
+template <> struct Bfly<20> : BflyPFA<4, 5> {};
+template <> struct Bfly<24> : BflyPFA<8, 3> {};
+
+/* Squares of odd primes: Cooley-Tukey A x A (input j = i + A j2, output k = k2 + A k1)
+   with the constants w_N^(i k2) */
+template <int N> struct CtTw;
+template <> struct CtTw<9> {
+    static FA_DEV cplx w(int k) {
+        const cplx t[5] = {
+            c_make(1.0, 0.0),
+            /* w9^1 */ c_make(0.7660444431189780352023926505554166739358, 0.6427876096865393263226434099072634329076),
+            /* w9^2 */ c_make(0.1736481776669303488517166267693147960004, 0.9848077530122080593667430245895230136706),
+            c_make(-0.5, 0.8660254037844386467637231707529361834714),
+            /* w9^4 */ c_make(-0.9396926207859083840541092773247314699362, 0.3420201433256687330440996146822595807631) };
+        return t[k];
+    }
+};
+template <> struct CtTw<25> {
+    static FA_DEV cplx w(int k) {
+        switch (k) {
+        case 1: return c_make(0.9685831611286311194901683754647358138360, 0.2486898871648547882422837460064479684176);
+        case 2: return c_make(0.8763066800438635873081159039220625833991, 0.4817536741017152749871915028721296535285);
+        case 3: return c_make(0.7289686274214115231467303190552591113726, 0.6845471059286886737322833576212092698895);
+        case 4: return c_make(0.5358267949789966182713087678676399780636, 0.8443279255020150785485580639666815053817);
+        case 6: return c_make(0.0627905195293133760761782245656311331225, 0.9980267284282715619523368068634505533369);
+        case 8: return c_make(-0.4257792915650726488625024457442517039800, 0.9048270524660195277136686479326975939704);
+        case 9: return c_make(-0.6374239897486897101767128116760161954349, 0.7705132427757892308030096363961778472717);
+        case 12: return c_make(-0.9921147013144778310497930427857785214530, 0.1253332335643042453731187598165087939429);
+        case 16: return c_make(-0.6374239897486897101767128116760161954349, -0.7705132427757892308030096363961778472717);
+        default: return c_make(1.0, 0.0);
+        }
+    }
+};
+template <int A> struct BflySquare {
+    static constexpr int N = A * A;
+    static FA_DEV void run(cplx *x) {
+        cplx z[A][A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+#pragma unroll
+            for (int j = 0; j < A; ++j) z[i][j] = x[i + A * j];
+            Bfly<A>::run(z[i]);
+        }
+#pragma unroll
+        for (int i = 1; i < A; ++i)
+#pragma unroll
+            for (int k2 = 1; k2 < A; ++k2) z[i][k2] = c_mulc(z[i][k2], CtTw<N>::w(i * k2));
+#pragma unroll
+        for (int k2 = 0; k2 < A; ++k2) {
+            cplx c[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) c[i] = z[i][k2];
+            Bfly<A>::run(c);
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) x[k2 + A * k1] = c[k1];
+        }
+    }
+};
+template <> struct Bfly<9> : BflySquare<3> {};
+template <> struct Bfly<25> : BflySquare<5> {};
+
 #endif /* FA_BUTTERFLIES_H */

@@ -1,6 +1,9 @@
 /*
  * kernels_rr.hip -- instantiations and launcher of the two-stage register
- * kernels for L = 64, 128, 256, 512 (passrr.hpp).  A translation unit of its
+ * kernels (passrr.hpp) for every length of rr_menu.inc: the powers of two 64 ... 512
+ * and the mixed-radix lengths whose (R1, R2) split tools/gen_rr_menu.py found to
+ * compile without register spills (X(L, R1, R2) entries; the reference's counterpart
+ * is its codelet list, fftw/dft_scalar/codelets/codlist.c).  A translation unit of its
  * own so that it compiles in parallel with kernels.hip.
  */
 #include "common.hpp"
@@ -48,15 +51,8 @@ int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *con
     if (d->src_im != 1 || d->dst_im != 1 ||
         (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
         return 1;
-    switch (d->L) {
-    case 64:  T = RRGeom<8, 8>::T; break;
-    case 128: T = RRGeom<16, 8>::T; break;
-    case 256: T = RRGeom<16, 16>::T; break;
-    case 512: T = RRGeom<32, 16>::T; break;
-    case 143: T = RRGeom<11, 13>::T; break;
-    case 105: T = RRGeom<15, 7>::T; break;
-    default: return 1;
-    }
+    T = fa_hip_rr_tile(d->L);
+    if (T <= 0) return 1;
     if (d->tile != T) return 1;                  /* the planner sized the step for another kernel */
     for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
         pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
@@ -102,12 +98,9 @@ int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *con
     bool out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);
     int tw = d->tw_n == 0 ? 0 : ((d->flags & FFTW_AMD_F_TW_IN) ? 2 : 1);
     switch (d->L) {
-    case 64:  return dispatch_rr<8, 8>(pa, grid, st, in_t, out_t, tw);
-    case 128: return dispatch_rr<16, 8>(pa, grid, st, in_t, out_t, tw);
-    case 256: return dispatch_rr<16, 16>(pa, grid, st, in_t, out_t, tw);
-    case 512: return dispatch_rr<32, 16>(pa, grid, st, in_t, out_t, tw);
-    case 143: return dispatch_rr<11, 13>(pa, grid, st, in_t, out_t, tw);
-    case 105: return dispatch_rr<15, 7>(pa, grid, st, in_t, out_t, tw);
+#define X(L_, R1_, R2_) case L_: return dispatch_rr<R1_, R2_>(pa, grid, st, in_t, out_t, tw);
+#include "rr_menu.inc"
+#undef X
     }
     return 1;
 }
@@ -167,12 +160,9 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
 /* tile width the register kernels use for a sub-transform length (0: none) */
 extern "C" int fa_hip_rr_tile(int L) {
     switch (L) {
-    case 64:  return RRGeom<8, 8>::T;
-    case 128: return RRGeom<16, 8>::T;
-    case 256: return RRGeom<16, 16>::T;
-    case 512: return RRGeom<32, 16>::T;
-    case 143: return RRGeom<11, 13>::T;
-    case 105: return RRGeom<15, 7>::T;
+#define X(L_, R1_, R2_) case L_: return RRGeom<R1_, R2_>::T;
+#include "rr_menu.inc"
+#undef X
     }
     return 0;
 }

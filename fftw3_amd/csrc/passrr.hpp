@@ -62,6 +62,9 @@ template <int R, int D, bool HAVE, bool PERM> struct TwTreeR<R, -1, D, HAVE, PER
 #ifndef FA_RR_SMALL_MAXL
 #define FA_RR_SMALL_MAXL 256
 #endif
+#ifndef FA_RR_WG3_MAX
+#define FA_RR_WG3_MAX 16
+#endif
 #ifndef FA_RR_SMALL_WGS
 #define FA_RR_SMALL_WGS 4
 #endif
@@ -71,23 +74,26 @@ template <int R, int D, bool HAVE, bool PERM> struct TwTreeR<R, -1, D, HAVE, PER
 constexpr bool fa_rr_small(int R1, int R2) {
     return ((R1 & (R1 - 1)) == 0) && ((R2 & (R2 - 1)) == 0) && R1 * R2 <= FA_RR_SMALL_MAXL;
 }
+/* elements an item may hold in a stage of radix R: powers of two 32; the odd and
+   composite butterflies need more temporaries (measured: 33 / 39 elements spill
+   150-200 VGPRs), the 3 x 5 radix 15 carries a scratch array (one butterfly per item) */
+constexpr int fa_rr_lim(int R, bool first) {
+    return R == 32 ? 32 : (R == 15 ? 15 : (first ? 30 : 28));
+}
+constexpr int fa_rr_q(int R_other, int T) { return (R_other * T + 255) / 256; }
 constexpr int fa_rr_tile(int R1, int R2) {
     if (fa_rr_small(R1, R2)) return FA_RR_SMALL_ELEMS / (R1 * R2);
     int T = 8192 / (R1 * R2);
-    /* powers of two run with exactly 32 elements per item; the odd-prime butterflies
-       need more temporaries, so their items keep at most 30 / 28 elements (measured:
-       33 / 39 elements spill 150-200 VGPRs) */
-    const bool pow2 = ((R1 & (R1 - 1)) == 0) && ((R2 & (R2 - 1)) == 0);
-    /* the composite radix 15 carries a 3 x 5 scratch array: one butterfly per item */
-    const int lim1 = pow2 ? 32 : (R1 == 15 ? 15 : 30), lim2 = pow2 ? 32 : (R2 == 15 ? 15 : 28);
-    while (T > 1 && ((((R2 * T + 255) / 256) * R1 > lim1) || (((R1 * T + 255) / 256) * R2 > lim2))) --T;
+    while (T > 1 && (fa_rr_q(R2, T) * R1 > fa_rr_lim(R1, true) || fa_rr_q(R1, T) * R2 > fa_rr_lim(R2, false))) --T;
     return T;
 }
 
 /* workgroups per CU the register budget is compiled for: 4 for the 16-element tiles,
-   3 when the tile is small enough that three images fit the LDS (105 = 15 x 7), else 2 */
+   3 when no item holds more than 16 elements in either stage, else 2 */
 constexpr int fa_rr_wgs(int R1, int R2) {
-    return fa_rr_small(R1, R2) ? FA_RR_SMALL_WGS : (R1 * R2 * fa_rr_tile(R1, R2) <= 4096 ? 3 : 2);
+    if (fa_rr_small(R1, R2)) return FA_RR_SMALL_WGS;
+    int T = fa_rr_tile(R1, R2);
+    return (fa_rr_q(R2, T) * R1 <= FA_RR_WG3_MAX && fa_rr_q(R1, T) * R2 <= FA_RR_WG3_MAX) ? 3 : 2;
 }
 
 template <int R1, int R2> struct RRGeom {

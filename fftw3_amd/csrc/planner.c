@@ -759,6 +759,30 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     if (ax.nloops == 0 && !contiguous) lmax1 = FA_LMAX_SINGLE;
     k = fa_factor_passes_pref(ax.n, FA_MAXPASS, lmax1, contiguous ? p->cfg.lmax_multi : FA_TILE_ELEMS / 8, lens,
                               getenv("FFTW_AMD_NO_TUNED") ? NULL : has_register_kernel);
+    {
+        /* test hook: FFTW_AMD_FORCE_LENS="L1,L2,..." fixes the split of the axis whose length
+           is the product (tests/test_gpu_menu.py reaches every kernel variant with it) */
+        const char *e = getenv("FFTW_AMD_FORCE_LENS");
+        if (e && *e) {
+            i64 fl[FA_MAXPASS], prod = 1;
+            int fk = 0;
+            const char *c = e;
+            while (*c && fk < FA_MAXPASS) {
+                char *end;
+                long long v = strtoll(c, &end, 10);
+                if (end == c || v < 1) { fk = 0; break; }
+                fl[fk++] = v;
+                prod *= v;
+                c = (*end == ',') ? end + 1 : end;
+                if (*end && *end != ',') { fk = 0; break; }
+            }
+            if (fk >= 2 && prod == ax.n) {
+                int a;
+                k = fk;
+                for (a = 0; a < fk; ++a) lens[a] = fl[a];
+            }
+        }
+    }
     if (k == 0) {
         /* e.g. a prime factor between lmax and FA_PRIME_LDS_MAX cannot happen;
            sizes that do not split fall back to Bluestein */

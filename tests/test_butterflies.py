@@ -26,7 +26,9 @@ extern "C" int bfly(int r, double *d) {
     case 2: run<2>(d); break; case 3: run<3>(d); break; case 4: run<4>(d); break;
     case 5: run<5>(d); break; case 7: run<7>(d); break; case 8: run<8>(d); break;
     case 11: run<11>(d); break; case 13: run<13>(d); break; case 16: run<16>(d); break;
-    case 15: run<15>(d); break;
+    case 15: run<15>(d); break; case 6: run<6>(d); break; case 9: run<9>(d); break;
+    case 10: run<10>(d); break; case 12: run<12>(d); break; case 14: run<14>(d); break;
+    case 20: run<20>(d); break; case 24: run<24>(d); break; case 25: run<25>(d); break;
     default: return -1;
     }
     return 0;
@@ -44,7 +46,7 @@ def test_butterflies_match_dft():
         lib = C.CDLL(so)
         lib.bfly.argtypes = [C.c_int, C.c_void_p]
         rng = np.random.default_rng(0)
-        for r in (2, 3, 4, 5, 7, 8, 11, 13, 15, 16):
+        for r in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 25):
             for _ in range(3):
                 x = rng.random(r) - 0.5 + 1j * (rng.random(r) - 0.5)
                 d = x.copy()

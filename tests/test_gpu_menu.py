@@ -1,0 +1,79 @@
+"""Every two-stage register kernel of fftw3_amd/csrc/rr_menu.inc, in every lane-mapping /
+twiddle variant the planner can emit, against the oracle:
+  (L,L,0)  contiguous single pass            n = L, howmany = 300
+  (T,T,0)  single column pass                n = L, interleaved batch (stride = howmany)
+  (T,T,0) + (L,T,2)  two-pass plan           n = L * L
+  (T,T,1) x2 and (L,T,0)                     forced splits L x L x 8 and 8 x 8 x L
+and that the plan really uses the register kernel for that length."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fftw3_amd as fa
+from util import ROOT, TOL, aerror, crand, oracle_dft
+
+pytestmark = pytest.mark.gpu
+
+
+def menu():
+    out = []
+    with open(os.path.join(ROOT, "fftw3_amd", "csrc", "rr_menu.inc")) as f:
+        for m in re.finditer(r"X\((\d+), (\d+), (\d+)\)", f.read()):
+            out.append(tuple(int(v) for v in m.groups()))
+    return out
+
+
+MENU = menu()
+
+
+def _run(n, hm, stride, dist):
+    import torch
+    rng = np.random.default_rng(n + hm)
+    x = crand(rng, hm * n)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros_like(xd)
+    p = fa.plan_many_dft(1, [n], hm, xd, None, stride, dist, yd, None, stride, dist, fa.FORWARD)
+    p.execute()
+    p.sync()
+    want = np.zeros_like(x)
+    oracle_dft(x, (n,), hm, out=want, istride=stride, idist=dist, ostride=stride, odist=dist)
+    return p, aerror(yd.cpu().numpy(), want)
+
+
+def test_menu_is_complete_and_consistent():
+    assert len(MENU) >= 60
+    for L, r1, r2 in MENU:
+        assert r1 * r2 == L
+
+
+@pytest.mark.parametrize("L,r1,r2", MENU, ids=[str(m[0]) for m in MENU])
+def test_single_pass_rows_and_columns(L, r1, r2):
+    p, e = _run(L, 300, 1, L)
+    assert "pass-%d/reg2" % L in p.sprint(), p.sprint()
+    assert e <= TOL, (L, e)
+    p, e = _run(L, 300, 300, 1)
+    assert "pass-%d/reg2" % L in p.sprint(), p.sprint()
+    assert e <= TOL, (L, e)
+
+
+@pytest.mark.parametrize("L,r1,r2", MENU, ids=[str(m[0]) for m in MENU])
+def test_two_pass_square(L, r1, r2):
+    p, e = _run(L * L, 3, 1, L * L)
+    s = p.sprint()
+    assert s.count("pass-%d/reg2" % L) == 2 or L * L <= 4096, s
+    assert e <= TOL, (L, e)
+
+
+@pytest.mark.parametrize("L,r1,r2", MENU, ids=[str(m[0]) for m in MENU])
+def test_three_pass_output_twiddle_and_last_pass_variants(L, r1, r2, monkeypatch):
+    """(T,T,1): first two passes of a forced L x L x 8 split; (L,T,0): last pass of 8 x 8 x L"""
+    monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "%d,%d,8" % (L, L))
+    p, e = _run(L * L * 8, 1, 1, L * L * 8)
+    assert p.sprint().count("pass-%d/reg2" % L) == 2, p.sprint()
+    assert e <= TOL, (L, e)
+    monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "8,8,%d" % L)
+    p, e = _run(64 * L, 40, 1, 64 * L)
+    assert "pass-%d/reg2" % L in p.sprint(), p.sprint()
+    assert e <= TOL, (L, e)
