@@ -463,6 +463,7 @@ static void emit_copy(plan *p, int kind, fa_loc src, fa_loc dst, i64 K, i64 Kval
 /* ------------------------------------------------------------- one axis */
 
 static void fa_emit_axis(plan *p, const fa_axis *ax);
+static int has_register_kernel(i64 L);
 
 static int loops_to_sdims(const fa_axis *ax, sdim *d, int use_dst_as_src) {
     int i;
@@ -745,6 +746,8 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
        in 128-byte segments; a contiguous axis may fill the tile by itself. */
     contiguous = (iabs(ax.is) <= 2 && iabs(ax.os) <= 2) || ax.dense;
     lmax1 = contiguous ? FA_LMAX_SINGLE : FA_TILE_ELEMS / 8;
+    /* a strided axis with a register kernel of its own length needs no split either */
+    if (!contiguous && ax.n <= 1024 && !getenv("FFTW_AMD_NO_TUNED") && has_register_kernel(ax.n)) lmax1 = 1024;
     /* powers of two above 1024 run faster as two register-kernel passes than
        as one LDS-sized pass (measured: 4096-point rows 0.8 TB/s vs ~5 TB/s per pass) */
     if (contiguous && ax.n > 1024 && (ax.n & (ax.n - 1)) == 0 && ax.nloops > 0 &&
