@@ -3,7 +3,7 @@ twiddle variant the planner can emit, against the oracle:
   (L,L,0)  contiguous single pass            n = L, howmany = 300
   (T,T,0)  single column pass                n = L, interleaved batch (stride = howmany)
   (T,T,0) + (L,T,2)  two-pass plan           n = L * L
-  (T,T,1) x2 and (L,T,0)                     forced splits L x L x 8 (or 64) and 8 x 8 x L
+  (T,T,1) x2 and (L,T,0)                     forced splits L x L x 8 (or 64) and 64 x 8 x L
 and that the plan really uses the register kernel for that length."""
 import os
 import re
@@ -68,13 +68,13 @@ def test_two_pass_square(L, r1, r2):
 
 @pytest.mark.parametrize("L,r1,r2", MENU, ids=[str(m[0]) for m in MENU])
 def test_three_pass_output_twiddle_and_last_pass_variants(L, r1, r2, monkeypatch):
-    """(T,T,1): first two passes of a forced L x L x 8 split; (L,T,0): last pass of 8 x 8 x L"""
+    """(T,T,1): first two passes of a forced L x L x 8 split; (L,T,0): last pass of 64 x 8 x L"""
     m = 8 if L > 100 else 64          # the middle pass needs enough sequences to fill a tile
     monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "%d,%d,%d" % (L, L, m))
     p, e = _run(L * L * m, 1, 1, L * L * m)
     assert p.sprint().count("pass-%d/reg2" % L) == 2, p.sprint()
     assert e <= TOL, (L, e)
-    monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "8,8,%d" % L)
-    p, e = _run(64 * L, 40, 1, 64 * L)
+    monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "64,8,%d" % L)
+    p, e = _run(512 * L, 4, 1, 512 * L)
     assert "pass-%d/reg2" % L in p.sprint(), p.sprint()
     assert e <= TOL, (L, e)
