@@ -72,7 +72,7 @@ def test_three_pass_output_twiddle_and_last_pass_variants(L, r1, r2, monkeypatch
     m = 8 if L > 100 else 64          # the middle pass needs enough sequences to fill a tile
     monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "%d,%d,%d" % (L, L, m))
     p, e = _run(L * L * m, 1, 1, L * L * m)
-    assert p.sprint().count("pass-%d/reg2" % L) == 2, p.sprint()
+    assert p.sprint().count("pass-%d/reg2" % L) >= 2, p.sprint()
     assert e <= TOL, (L, e)
     monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "64,8,%d" % L)
     p, e = _run(512 * L, 4, 1, 512 * L)
