@@ -69,7 +69,7 @@ def test_two_pass_square(L, r1, r2):
 @pytest.mark.parametrize("L,r1,r2", MENU, ids=[str(m[0]) for m in MENU])
 def test_three_pass_output_twiddle_and_last_pass_variants(L, r1, r2, monkeypatch):
     """(T,T,1): first two passes of a forced L x L x 8 split; (L,T,0): last pass of 64 x 8 x L"""
-    m = 8 if L > 100 else 64          # the middle pass needs enough sequences to fill a tile
+    m = 8 if L > 200 else 64          # the middle pass needs enough sequences to fill a tile
     monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "%d,%d,%d" % (L, L, m))
     p, e = _run(L * L * m, 1, 1, L * L * m)
     assert p.sprint().count("pass-%d/reg2" % L) >= 2, p.sprint()
