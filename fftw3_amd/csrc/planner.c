@@ -760,6 +760,16 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
         if (!rows3s) lmax1 = 1024;
     }
     if (ax.nloops == 0 && !contiguous) lmax1 = FA_LMAX_SINGLE;
+    /* 1024 < n <= 4096 that is not a power of two: two register-kernel passes (each near
+       the copy rate) beat one pass of the LDS kernel (1.3-1.8 TB/s) whenever both halves of
+       a balanced split have a register kernel -- measured n = 3000: 1.27 vs 2.4 TB/s */
+    if (contiguous && ax.n > 1024 && ax.n <= lmax1 && (ax.n & (ax.n - 1)) != 0 && ax.nloops > 0 &&
+        !getenv("FFTW_AMD_NO_TUNED")) {
+        i64 l2[FA_MAXPASS];
+        if (fa_factor_passes_pref(ax.n, 2, 1, 1024, l2, has_register_kernel) == 2 &&
+            has_register_kernel(l2[0]) && has_register_kernel(l2[1]))
+            lmax1 = 1024;
+    }
     k = fa_factor_passes_pref(ax.n, FA_MAXPASS, lmax1, contiguous ? p->cfg.lmax_multi : FA_TILE_ELEMS / 8, lens,
                               getenv("FFTW_AMD_NO_TUNED") ? NULL : has_register_kernel);
     {

@@ -1,7 +1,7 @@
 """exploration: throughput of sizes without a register kernel (not a test)"""
 import time, torch
 import fftw3_amd as fa
-for n in (1000, 1536, 1920, 3000, 5000, 10000, 60060, 100000, 5 ** 8):
+for n in (1000, 1536, 1920, 2000, 2400, 3000, 3600, 4000, 5000, 10000, 60060, 100000, 360, 720, 1080):
     hm = max(1, (1 << 29) // (16 * n) * 2)          # ~1 GiB of input
     x = torch.view_as_complex(torch.rand((hm * n, 2), dtype=torch.float64, device="cuda") - 0.5)
     y = torch.zeros_like(x)
