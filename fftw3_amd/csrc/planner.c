@@ -25,7 +25,8 @@ typedef struct fftw_plan_s plan;
 
 static size_t g_chunk_bytes = (size_t)1 << 30;
 static i64 g_lmax_multi = 1024;
-static int g_pipeline = 1;
+static int g_pipeline = 0;   /* two-stream chunk pipeline: off under FFTW_ESTIMATE (each kernel then owns the machine and
+                                  its launch duration is its roofline), a FFTW_MEASURE candidate, FFTW_AMD_PIPELINE=1 */
 static int g_small_tiles = 1;
 static int g_long_first = 0;
 static i64 g_tile_elems = 0;

@@ -326,6 +326,48 @@ def test_chunked_batches_and_ragged_tail(torch_dev):
         fa.set_chunk_bytes(0)
 
 
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+def test_chunk_pipeline_on_and_off(torch_dev, monkeypatch, pipeline):
+    """the two-stream chunk pipeline (a FFTW_MEASURE candidate, FFTW_AMD_PIPELINE=1) and the
+    serial default give the same transforms: c2c two-pass, r2c, r2r, in place and out of place"""
+    from util import oracle_r2c, oracle_r2r, rrand
+    torch, dev = torch_dev
+    rng = np.random.default_rng(40)
+    monkeypatch.setenv("FFTW_AMD_PIPELINE", pipeline)
+    fa.set_chunk_bytes(8 << 20)
+    try:
+        n, b = 1 << 16, 37                     # 1 MiB per transform: chunk 4 .. 8, ragged tail
+        x = crand(rng, b, n)
+        xd = torch.from_numpy(x).to(dev)
+        yd = torch.zeros_like(xd)
+        p = fa.plan_many_dft(1, [n], b, xd, None, 1, n, yd, None, 1, n, fa.FORWARD)
+        assert p.chunk < b
+        p.execute()
+        torch.cuda.synchronize()
+        assert aerror(yd.cpu().numpy(), oracle_dft(x, (n,), b).reshape(b, n)) < TOL
+        q = fa.plan_many_dft(1, [n], b, xd, None, 1, n, xd, None, 1, n, fa.FORWARD)   # in place
+        q.execute()
+        torch.cuda.synchronize()
+        assert aerror(xd.cpu().numpy(), oracle_dft(x, (n,), b).reshape(b, n)) < TOL
+        xr = rrand(rng, b, n)
+        xrd = torch.from_numpy(xr).to(dev)
+        yrd = torch.zeros((b, n // 2 + 1), dtype=torch.complex128, device=dev)
+        r = fa.plan_many_dft_r2c(1, [n], b, xrd, None, 1, n, yrd, None, 1, n // 2 + 1)
+        r.execute()
+        torch.cuda.synchronize()
+        assert aerror(yrd.cpu().numpy(), oracle_r2c(xr, (n,), b).reshape(b, n // 2 + 1)) < TOL
+        zrd = torch.zeros_like(xrd)
+        t = fa.plan_many_r2r(1, [n], b, xrd, None, 1, n, zrd, None, 1, n, [fa.REDFT10])
+        t.execute()
+        torch.cuda.synchronize()
+        assert aerror(zrd.cpu().numpy().reshape(-1), oracle_r2r(xr.reshape(-1), [n], [fa.REDFT10], howmany=b)) < TOL
+    finally:
+        fa.set_chunk_bytes(0)
+        monkeypatch.setenv("FFTW_AMD_PIPELINE", "0")
+        z = np.zeros(4, dtype=np.complex128)
+        fa.plan_dft_1d(4, z, z, fa.FORWARD)        # re-reads the environment
+
+
 def _gpu_apply(torch_dev, shape, sign=-1):
     torch, dev = torch_dev
     cache = {}
