@@ -76,6 +76,7 @@ class StepDesc(C.Structure):
         ("aux_buf", C.c_int), ("aux_base", C.c_longlong),
         ("variant", C.c_int),
         ("tile_lo_n", C.c_int), ("tile_lo_is", C.c_longlong), ("tile_lo_os", C.c_longlong),
+        ("kpos", C.c_int),
     ]
 
 

@@ -349,6 +349,7 @@ struct RealArgs {
     const cplx *tw_hi;
     int tw_shift;
     int ndims, flags;
+    int kpos;    /* dims [0, kpos) are peeled before the pair index */
     int r2r;     /* fused r2r epilogue (r2c) / prologue (c2r): FFTW_AMD_R2R_* or 0 */
     int twmul;   /* untangle twiddle w_n^k = table entry k * twmul */
     i64 rn;      /* r2r length */
@@ -427,14 +428,15 @@ __global__ void __launch_bounds__(256) r2c_post_kernel(const RealArgs a) {
     i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     i64 stride = (i64)gridDim.x * blockDim.x;
     for (; gid < a.total; gid += stride) {
-        i64 k = gid % a.npair;
-        i64 rest = gid / a.npair;
-        i64 soff = 0, doff = 0;
-        for (int d = 0; d < a.ndims; ++d) {
-            i64 idx = rest % a.dn[d];
-            rest /= a.dn[d];
-            soff += idx * a.dis[d];
-            doff += idx * a.dos[d];
+        i64 rest = gid, k = 0, soff = 0, doff = 0;
+        for (int d = 0; d <= a.ndims; ++d) {
+            if (d == a.kpos) { k = rest % a.npair; rest /= a.npair; }
+            if (d < a.ndims) {
+                i64 idx = rest % a.dn[d];
+                rest /= a.dn[d];
+                soff += idx * a.dis[d];
+                doff += idx * a.dos[d];
+            }
         }
         i64 km = a.h - k;
         cplx zk = load_elem<false>(a.src, soff + k * a.is_k, a.src_im, 0);
@@ -460,14 +462,15 @@ __global__ void __launch_bounds__(256) c2r_pre_kernel(const RealArgs a) {
     i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     i64 stride = (i64)gridDim.x * blockDim.x;
     for (; gid < a.total; gid += stride) {
-        i64 k = gid % a.npair;
-        i64 rest = gid / a.npair;
-        i64 soff = 0, doff = 0;
-        for (int d = 0; d < a.ndims; ++d) {
-            i64 idx = rest % a.dn[d];
-            rest /= a.dn[d];
-            soff += idx * a.dis[d];
-            doff += idx * a.dos[d];
+        i64 rest = gid, k = 0, soff = 0, doff = 0;
+        for (int d = 0; d <= a.ndims; ++d) {
+            if (d == a.kpos) { k = rest % a.npair; rest /= a.npair; }
+            if (d < a.ndims) {
+                i64 idx = rest % a.dn[d];
+                rest /= a.dn[d];
+                soff += idx * a.dis[d];
+                doff += idx * a.dos[d];
+            }
         }
         i64 km = a.h - k;
         cplx yk = pro_load(a, soff, k);
@@ -684,7 +687,7 @@ struct Real4Args {
     const cplx *tw_hi;
     int tw_shift;
     int ndims, flags;
-    int r2r, twmul;      /* as in RealArgs */
+    int kpos, r2r, twmul;      /* as in RealArgs */
     i64 rn;
 };
 
@@ -692,14 +695,15 @@ __global__ void __launch_bounds__(256) r2c_post4_kernel(const Real4Args a) {
     i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     i64 stride = (i64)gridDim.x * blockDim.x;
     for (; gid < a.total; gid += stride) {
-        i64 k = gid % a.npair;
-        i64 rest = gid / a.npair;
-        i64 soff = 0, doff = 0;
-        for (int d = 0; d < a.ndims; ++d) {
-            i64 idx = rest % a.dn[d];
-            rest /= a.dn[d];
-            soff += idx * a.dis[d];
-            doff += idx * a.dos[d];
+        i64 rest = gid, k = 0, soff = 0, doff = 0;
+        for (int d = 0; d <= a.ndims; ++d) {
+            if (d == a.kpos) { k = rest % a.npair; rest /= a.npair; }
+            if (d < a.ndims) {
+                i64 idx = rest % a.dn[d];
+                rest /= a.dn[d];
+                soff += idx * a.dis[d];
+                doff += idx * a.dos[d];
+            }
         }
         const i64 m = a.m, km = (k == 0) ? 0 : m - k;
         cplx T[4];
@@ -748,14 +752,15 @@ __global__ void __launch_bounds__(256) c2r_pre4_kernel(const Real4Args a) {
     i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     i64 stride = (i64)gridDim.x * blockDim.x;
     for (; gid < a.total; gid += stride) {
-        i64 k = gid % a.npair;
-        i64 rest = gid / a.npair;
-        i64 soff = 0, doff = 0;
-        for (int d = 0; d < a.ndims; ++d) {
-            i64 idx = rest % a.dn[d];
-            rest /= a.dn[d];
-            soff += idx * a.dis[d];
-            doff += idx * a.dos[d];
+        i64 rest = gid, k = 0, soff = 0, doff = 0;
+        for (int d = 0; d <= a.ndims; ++d) {
+            if (d == a.kpos) { k = rest % a.npair; rest /= a.npair; }
+            if (d < a.ndims) {
+                i64 idx = rest % a.dn[d];
+                rest /= a.dn[d];
+                soff += idx * a.dis[d];
+                doff += idx * a.dos[d];
+            }
         }
         const i64 m = a.m;
         /* the four half-spectrum entries this pair needs (src here is Y, is_k its stride) */
@@ -1261,6 +1266,7 @@ extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bu
         ra.os_k = d->os_l;
         ra.h = d->aux_n / 2;
         ra.npair = ra.h / 2 + 1;
+        ra.kpos = d->kpos;
         ra.r2r = d->variant;
         ra.twmul = d->tile > 0 ? d->tile : 1;
         ra.rn = r2r_len_of(d->variant, d->aux_n);
@@ -1304,6 +1310,7 @@ extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bu
         ra.os_k = d->os_l;
         ra.vs = d->aux_valid;            /* distance between the two quarter-length vectors */
         ra.m = d->aux_n / 4;
+        ra.kpos = d->kpos;
         ra.r2r = d->variant;
         ra.twmul = d->tile > 0 ? d->tile : 1;
         ra.rn = r2r_len_of(d->variant, d->aux_n);
@@ -1351,7 +1358,7 @@ extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bu
         ra.tw_hi = (d->tw_hi >= 0) ? (const cplx *)tables[d->tw_hi] : NULL;
         ra.tw_shift = d->tw_shift;
         ra.ndims = d->ndims;
-        ra.kpos = d->tile;
+        ra.kpos = d->kpos;
         ra.mode = d->variant;
         i64 total = ra.K;
         for (int i = 0; i < d->ndims; ++i) total *= ra.dn[i];

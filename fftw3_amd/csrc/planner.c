@@ -329,6 +329,30 @@ static int step_set_dims(plan *p, fftw_amd_step_desc *s, const sdim *d, int nd, 
     return 0;
 }
 
+
+/* Order the loops of an element-wise step by their stride on the user side (by_dst: the
+   destination, else the source), the batch loop last, and return how many of them are
+   faster than the transform index of stride kstride (step.kpos).  Extent-1 loops drop out
+   here so that the count matches what step_set_dims keeps. */
+static int order_dims_kpos(sdim *d, int *nd_io, int by_dst, i64 kstride) {
+    sdim t[FA_MAXLOOPS + 1], b;
+    int nd = *nd_io, cnt = 0, i, j, have_b = 0, kpos = 0;
+    for (i = 0; i < nd; ++i) {
+        i64 key;
+        if (d[i].is_batch) { b = d[i]; have_b = 1; continue; }
+        if (d[i].n == 1) continue;
+        key = iabs(by_dst ? d[i].os : d[i].is);
+        for (j = cnt - 1; j >= 0 && iabs(by_dst ? t[j].os : t[j].is) > key; --j) t[j + 1] = t[j];
+        t[j + 1] = d[i];
+        ++cnt;
+    }
+    for (i = 0; i < cnt; ++i) if (iabs(by_dst ? t[i].os : t[i].is) < iabs(kstride)) kpos = i + 1;
+    if (have_b) t[cnt++] = b;
+    memcpy(d, t, sizeof(sdim) * (size_t)cnt);
+    *nd_io = cnt;
+    return kpos;
+}
+
 /* One batched length-L DFT pass.  dims: every index other than the transform
    index.  The tile dim is the one whose stride makes global access widest. */
 static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l,
@@ -995,6 +1019,7 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
             d[nd].n = ax.loops[j].n; d[nd].is = lts[j]; d[nd].os = ax.loops[j].os;
             d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
         }
+        s->kpos = order_dims_kpos(d, &nd, 1, cs);
         step_set_dims(p, s, d, nd, -1);
         p->est_flops += 20.0 * (double)m;
         buf_release(p, zbuf);
@@ -1033,6 +1058,7 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
             d[nd].n = ax.loops[j].n; d[nd].is = lts[j]; d[nd].os = ax.loops[j].os;
             d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
         }
+        s->kpos = order_dims_kpos(d, &nd, 1, cs);
         step_set_dims(p, s, d, nd, -1);
         p->est_flops += 8.0 * (double)h;
         buf_release(p, zbuf);
@@ -1140,6 +1166,7 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
             d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
             d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
         }
+        s->kpos = order_dims_kpos(d, &nd, 0, cs);
         step_set_dims(p, s, d, nd, -1);
 
         q_ax.n = m;
@@ -1178,6 +1205,7 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
             d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = lts[j];
             d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
         }
+        s->kpos = order_dims_kpos(d, &nd, 0, cs);
         step_set_dims(p, s, d, nd, -1);
 
         half_ax = ax;
@@ -1312,9 +1340,8 @@ static fftw_amd_step_desc *emit_r2r_step(plan *p, int mode, i64 n, i64 K, i64 tw
                                          const fa_axis *ax, const i64 *lis, const i64 *los,
                                          int order_by_dst) {
     fftw_amd_step_desc *s = new_step(p, FFTW_AMD_STEP_R2R);
-    sdim d[FA_MAXLOOPS];
-    int idx[FA_MAXLOOPS], cnt = 0, i, j, kpos = 0;
-    i64 key[FA_MAXLOOPS], akey = iabs(order_by_dst ? os_k : is_k);
+    sdim d[FA_MAXLOOPS + 1];
+    int cnt = 0, i;
     s->variant = mode;
     s->src_buf = src.buf; s->src_base = src.base; s->src_im = src.im;
     s->dst_buf = dst.buf; s->dst_base = dst.base; s->dst_im = dst.im;
@@ -1325,25 +1352,15 @@ static fftw_amd_step_desc *emit_r2r_step(plan *p, int mode, i64 n, i64 K, i64 tw
     if (twmod) tab_tw2(p, twmod, &s->tw_lo, &s->tw_hi, &s->tw_shift);
     /* flatten order: smallest user-side stride fastest, the batch loop last */
     for (i = 0; i < ax->nloops; ++i) {
-        i64 k;
-        if (i == ax->batch_loop || ax->loops[i].n == 1) continue;
-        k = iabs(order_by_dst ? los[i] : lis[i]);
-        for (j = cnt - 1; j >= 0 && key[j] > k; --j) { idx[j + 1] = idx[j]; key[j + 1] = key[j]; }
-        idx[j + 1] = i;
-        key[j + 1] = k;
+        d[cnt].n = ax->loops[i].n;
+        d[cnt].is = lis[i];
+        d[cnt].os = los[i];
+        d[cnt].tw = 0;
+        d[cnt].is_batch = (i == ax->batch_loop);
         ++cnt;
     }
-    for (i = 0; i < cnt; ++i) if (key[i] < akey) kpos = i + 1;
-    if (ax->batch_loop >= 0) idx[cnt++] = ax->batch_loop;
-    for (i = 0; i < cnt; ++i) {
-        d[i].n = ax->loops[idx[i]].n;
-        d[i].is = lis[idx[i]];
-        d[i].os = los[idx[i]];
-        d[i].tw = 0;
-        d[i].is_batch = (idx[i] == ax->batch_loop);
-    }
+    s->kpos = order_dims_kpos(d, &cnt, order_by_dst, order_by_dst ? os_k : is_k);
     step_set_dims(p, s, d, cnt, -1);
-    s->tile = kpos;
     p->est_flops += 4.0 * (double)K;
     return s;
 }

@@ -81,6 +81,11 @@ typedef struct {
        real transforms) share 16-byte-contiguous global accesses. */
     int tile_lo_n;
     long long tile_lo_is, tile_lo_os;
+    /* element-wise real-transform steps (untangle / tangle / r2r): the work items run over
+       dims[0..kpos), then the pair / transform index, then the remaining dims -- the planner
+       orders them by the user-side stride so that neighbouring items touch neighbouring
+       memory whichever axis is transformed */
+    int kpos;
 } fftw_amd_step_desc;
 
 enum {
@@ -96,7 +101,7 @@ enum {
 };
 
 /* FFTW_AMD_STEP_R2R modes (step.variant).  aux_n = r2r length n, aux_valid =
-   work items per transform, tile = position of the transform index among the
+   work items per transform, kpos = position of the transform index among the
    flattened loop indices, tw_* = two-level table of modulus 4n (01/10) or 8n (11).
    PRE_* map the user's real array into the inner transform's input, POST_* map
    the inner transform's output into the user's real array. */
