@@ -534,6 +534,10 @@ __global__ void __launch_bounds__(256) r2r_kernel(const R2RArgs a) {
 #define SI(j) S[(j) * a.is_k + a.src_im]
 #define DR(j) D[(j) * a.os_k]
 #define DI(j) D[(j) * a.os_k + a.dst_im]
+/* real sequences on the scratch side are addressed as pairs: element j at
+   (j >> 1) * stride + (j & 1) * im  (planner.c emit_r2r_axis) */
+#define DP(j) D[((j) >> 1) * a.os_k + ((j) & 1) * a.dst_im]
+#define SP(j) S[((j) >> 1) * a.is_k + ((j) & 1) * a.src_im]
         switch (a.mode) {
         case FFTW_AMD_R2R_PRE_HC2R: {
             DR(k) = SR(k);
@@ -543,10 +547,10 @@ __global__ void __launch_bounds__(256) r2r_kernel(const R2RArgs a) {
         case FFTW_AMD_R2R_PRE_E10:
         case FFTW_AMD_R2R_PRE_O10: {
             /* v[j] = x[2j], v[n-1-j] = x[2j+1]: one work item per input pair */
-            DR(k) = SR(2 * k);
+            DP(k) = SR(2 * k);
             if (2 * k + 1 < n) {
                 double b = SR(2 * k + 1);
-                DR(n - 1 - k) = (a.mode == FFTW_AMD_R2R_PRE_O10) ? -b : b;
+                DP(n - 1 - k) = (a.mode == FFTW_AMD_R2R_PRE_O10) ? -b : b;
             }
             break;
         }
@@ -562,7 +566,7 @@ __global__ void __launch_bounds__(256) r2r_kernel(const R2RArgs a) {
         }
         case FFTW_AMD_R2R_PRE_E00: {
             i64 N = 2 * (n - 1);
-            DR(k) = SR(k < n ? k : N - k);
+            DP(k) = SR(k < n ? k : N - k);
             break;
         }
         case FFTW_AMD_R2R_PRE_O00: {
@@ -570,7 +574,7 @@ __global__ void __launch_bounds__(256) r2r_kernel(const R2RArgs a) {
             double v = 0.0;
             if (k >= 1 && k <= n) v = SR(k - 1);
             else if (k > n + 1) v = -SR(N - k - 1);
-            DR(k) = v;
+            DP(k) = v;
             break;
         }
         case FFTW_AMD_R2R_PRE_E11:
@@ -624,9 +628,9 @@ __global__ void __launch_bounds__(256) r2r_kernel(const R2RArgs a) {
         case FFTW_AMD_R2R_POST_E01:
         case FFTW_AMD_R2R_POST_O01: {
             /* y[2j] = v[j], y[2j+1] = v[n-1-j]: one work item per output pair */
-            DR(2 * k) = SR(k);
+            DR(2 * k) = SP(k);
             if (2 * k + 1 < n) {
-                double b = SR(n - 1 - k);
+                double b = SP(n - 1 - k);
                 DR(2 * k + 1) = (a.mode == FFTW_AMD_R2R_POST_O01) ? -b : b;
             }
             break;
@@ -662,6 +666,8 @@ __global__ void __launch_bounds__(256) r2r_kernel(const R2RArgs a) {
 #undef SI
 #undef DR
 #undef DI
+#undef DP
+#undef SP
     }
 }
 

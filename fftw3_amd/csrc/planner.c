@@ -969,11 +969,17 @@ static void r2r_fuse_tables(plan *p, fftw_amd_step_desc *s, i64 nl, int mode) {
 /* epi: 0 = store the half spectrum as complex numbers; FFTW_AMD_R2R_POST_* = the
    untangle step applies that r2r epilogue and writes reals of stride cs instead
    (even lengths only; returns 1 when the epilogue was fused, 0 when the caller
-   still has to run it on the complex result) */
-static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs, fa_loc out, i64 cs, int epi) {
+   still has to run it on the complex result)
+   ps / pim (even lengths): the real input as pairs -- sample 2j at j*ps, sample 2j+1 at
+   j*ps + pim; 0 / 0 = the plain strided array (ps = 2 rs, pim = rs).  Scratch inputs of the
+   r2r emitters use ps = any, pim = 1: pairs stay adjacent even when other loops are
+   innermost, so the register kernels take the first pass. */
+static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs, fa_loc out, i64 cs, int epi,
+                         i64 ps, i64 pim) {
     fa_axis ax = *axp;
     i64 half = nl / 2 + 1;
     int j;
+    if (ps == 0) { ps = 2 * rs; pim = rs; }
     if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
         (axis_pass_count(nl / 4) < axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
         /* n = 4m: two complex DFTs of size m on (x[4j], x[4j+1]) and (x[4j+2], x[4j+3]),
@@ -988,7 +994,7 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
         /* scratch [loops][v][m]: the vector index v rides as the innermost loop */
         vloop = q_ax.nloops++;
         q_ax.loops[vloop].n = 2;
-        q_ax.loops[vloop].is = 2 * rs;
+        q_ax.loops[vloop].is = ps;
         q_ax.loops[vloop].os = 0;
         lay = q_ax;
         lay.is = 2;
@@ -996,12 +1002,12 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
         total = scratch_layout(&lay, m, &zts, lts);
         zbuf = buf_acquire(p, total);
         z.buf = zbuf; z.base = 0; z.im = 1;
-        q_ax.dense = (rs == 1);
+        q_ax.dense = (pim == 1 && ps == 2);
         q_ax.n = m;
-        q_ax.is = 4 * rs;
+        q_ax.is = 2 * ps;
         q_ax.os = zts;
         q_ax.src = in;
-        q_ax.src.im = rs;
+        q_ax.src.im = pim;
         q_ax.dst = z;
         for (j = 0; j < q_ax.nloops; ++j) q_ax.loops[j].os = lts[j];
         fa_emit_axis(p, &q_ax);
@@ -1038,10 +1044,10 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
         z.buf = zbuf; z.base = 0; z.im = 1;
 
         half_ax.n = h;
-        half_ax.is = 2 * rs;
+        half_ax.is = ps;
         half_ax.os = zts;
         half_ax.src = in;
-        half_ax.src.im = rs;     /* odd sample = imaginary part */
+        half_ax.src.im = pim;    /* odd sample = imaginary part */
         half_ax.dst = z;
         for (j = 0; j < ax.nloops; ++j) half_ax.loops[j].os = lts[j];
         fa_emit_axis(p, &half_ax);
@@ -1106,7 +1112,7 @@ static void build_r2c(plan *p) {
     memset(&ax, 0, sizeof(ax));
     if (collect_loops(p, p->dims, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
 
-    emit_r2c_axis(p, nl, &ax, in, p->dims[r - 1].is, out, p->dims[r - 1].os, 0);
+    emit_r2c_axis(p, nl, &ax, in, p->dims[r - 1].is, out, p->dims[r - 1].os, 0, 0, 0);
 
     for (a = r - 2; a >= 0; --a) {
         fa_axis cx;
@@ -1127,10 +1133,13 @@ static void build_r2c(plan *p) {
    destination); cs / rs: element strides of the transform index, in doubles. */
 /* pro: 0 = `cur` holds the half spectrum as complex numbers; FFTW_AMD_R2R_PRE_* =
    `cur` is the user's real r2r input of stride cs and the tangle step applies
-   that prologue while loading (even lengths only, see r2r_can_fuse) */
-static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 cs, fa_loc out, i64 rs, int pro) {
+   that prologue while loading (even lengths only, see r2r_can_fuse)
+   ps / pim: pair geometry of the real output, as in emit_r2c_axis */
+static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 cs, fa_loc out, i64 rs, int pro,
+                          i64 ps, i64 pim) {
     fa_axis ax = *axp;
     int j;
+    if (ps == 0) { ps = 2 * rs; pim = rs; }
     if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
         (axis_pass_count(nl / 4) < axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
         /* transpose of the radix-4 r2c plan: tangle into two quarter-length
@@ -1144,14 +1153,14 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         vloop = q_ax.nloops++;
         q_ax.loops[vloop].n = 2;
         q_ax.loops[vloop].is = 0;
-        q_ax.loops[vloop].os = 2 * rs;
+        q_ax.loops[vloop].os = ps;
         lay = q_ax;
         lay.is = 2;
         lay.loops[vloop].is = 1;
         total = scratch_layout(&lay, m, &zts, lts);
         zbuf = buf_acquire(p, total);
         z.buf = zbuf; z.base = 0; z.im = 1;
-        q_ax.dense = (rs == 1);
+        q_ax.dense = (pim == 1 && ps == 2);
 
         s = new_step(p, FFTW_AMD_STEP_C2R_PRE4);
         s->src_buf = cur.buf; s->src_base = cur.base; s->src_im = cur.im;
@@ -1171,10 +1180,10 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
 
         q_ax.n = m;
         q_ax.is = zts;
-        q_ax.os = 4 * rs;
+        q_ax.os = 2 * ps;
         q_ax.src = z;
         q_ax.dst = out;
-        q_ax.dst.im = rs;
+        q_ax.dst.im = pim;
         q_ax.flags_in = FFTW_AMD_F_SWAP_IN;
         q_ax.flags_out = FFTW_AMD_F_SWAP_OUT;
         for (j = 0; j < q_ax.nloops; ++j) q_ax.loops[j].is = lts[j];
@@ -1211,10 +1220,10 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         half_ax = ax;
         half_ax.n = h;
         half_ax.is = zts;
-        half_ax.os = 2 * rs;
+        half_ax.os = ps;
         half_ax.src = z;
         half_ax.dst = out;
-        half_ax.dst.im = rs;
+        half_ax.dst.im = pim;
         half_ax.flags_in = FFTW_AMD_F_SWAP_IN;
         half_ax.flags_out = FFTW_AMD_F_SWAP_OUT;
         for (j = 0; j < ax.nloops; ++j) half_ax.loops[j].is = lts[j];
@@ -1321,7 +1330,7 @@ static void build_c2r(plan *p) {
         if (collect_loops(&view, td, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
     }
 
-    emit_c2r_axis(p, nl, &ax, cur, cdims[r - 1].is, out, p->dims[r - 1].os, 0);
+    emit_c2r_axis(p, nl, &ax, cur, cdims[r - 1].is, out, p->dims[r - 1].os, 0, 0, 0);
     if (cbuf >= 0) buf_release(p, cbuf);
 }
 
@@ -1372,8 +1381,8 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
     int pre = 0, post = 0, inner = IN_R2C, j, nl = axp->nloops, fuse_pre = 0, fuse_post = 0;
     i64 N = n, cntA = 0, unitA = 1, cntB = 0, unitB = 1, twmod = 0, Kpre = 0, Kpost = 0;
     i64 lis_user[FA_MAXLOOPS], los_user[FA_MAXLOOPS], ltsA[FA_MAXLOOPS], ltsB[FA_MAXLOOPS];
-    i64 tsA = 0, tsB = 0;
-    int abuf = -1, bbuf = -1;
+    i64 tsA = 0, tsB = 0, psA = 0, pimA = 0, psB = 0, pimB = 0;
+    int abuf = -1, bbuf = -1, pairA = 0, pairB = 0;
     fa_loc A = { -1, 0, 1 }, B = { -1, 0, 1 };
     fa_axis lay, iax;
     for (j = 0; j < nl; ++j) { lis_user[j] = axp->loops[j].is; los_user[j] = axp->loops[j].os; }
@@ -1435,11 +1444,21 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
     if (inner == IN_R2C && post && r2r_can_fuse(N)) { fuse_post = 1; cntB = 0; }
     if (inner == IN_C2R && pre && r2r_can_fuse(N)) { fuse_pre = 1; cntA = 0; }
 
+    /* Real scratch sequences of even length are laid out as adjacent pairs
+       (sample 2j, 2j+1) = one interleaved complex number of stride ts: whatever loops end
+       up innermost, the inner real transform then reads / writes 16-byte elements and its
+       first / last pass can be a register kernel.  pairA / pairB = 1 marks that layout;
+       odd lengths keep a plain real stride (pair stride 2 ts, pair im ts). */
     if (cntA) {
         i64 total;
         lay = *axp;
         lay.is = rs;
-        total = scratch_layout_u(&lay, cntA, unitA, &tsA, ltsA);
+        if (unitA == 1 && cntA % 2 == 0) {
+            pairA = 1;
+            total = scratch_layout_u(&lay, cntA / 2, 2, &tsA, ltsA);
+        } else {
+            total = scratch_layout_u(&lay, cntA, unitA, &tsA, ltsA);
+        }
         abuf = buf_acquire(p, total);
         A.buf = abuf;
     }
@@ -1448,12 +1467,24 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
         lay = *axp;
         lay.is = os;
         for (j = 0; j < nl; ++j) lay.loops[j].is = los_user[j];
-        total = scratch_layout_u(&lay, cntB, unitB, &tsB, ltsB);
+        if (unitB == 1 && cntB % 2 == 0) {
+            pairB = 1;
+            total = scratch_layout_u(&lay, cntB / 2, 2, &tsB, ltsB);
+        } else {
+            total = scratch_layout_u(&lay, cntB, unitB, &tsB, ltsB);
+        }
         bbuf = buf_acquire(p, total);
         B.buf = bbuf;
     }
+    /* pair geometry as the steps see it: (pair stride, distance inside the pair) */
+    psA = (unitA == 1) ? (pairA ? tsA : 2 * tsA) : 0;  pimA = (unitA == 1) ? (pairA ? 1 : tsA) : 0;
+    psB = (unitB == 1) ? (pairB ? tsB : 2 * tsB) : 0;  pimB = (unitB == 1) ? (pairB ? 1 : tsB) : 0;
 
-    if (pre && !fuse_pre) emit_r2r_step(p, pre, n, Kpre, twmod, in, rs, A, tsA, axp, lis_user, ltsA, 0);
+    if (pre && !fuse_pre) {
+        fa_loc dA = A;
+        if (unitA == 1) dA.im = pimA;          /* real sequence: element j at (j >> 1) psA + (j & 1) pimA */
+        emit_r2r_step(p, pre, n, Kpre, twmod, in, rs, dA, unitA == 1 ? psA : tsA, axp, lis_user, ltsA, 0);
+    }
 
     iax = *axp;
     iax.flags_in = iax.flags_out = 0;
@@ -1466,10 +1497,10 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
         }
         s.im = 0;
         if (fuse_post) {
-            emit_r2c_axis(p, N, &iax, s, pre ? tsA : rs, out, os, post);
+            emit_r2c_axis(p, N, &iax, s, pre ? pimA : rs, out, os, post, pre ? psA : 0, pre ? pimA : 0);
             post = 0;
         } else {
-            emit_r2c_axis(p, N, &iax, s, pre ? tsA : rs, B, tsB, 0);
+            emit_r2c_axis(p, N, &iax, s, pre ? pimA : rs, B, tsB, 0, pre ? psA : 0, pre ? pimA : 0);
         }
     } else if (inner == IN_C2R) {
         fa_loc d = post ? B : out;
@@ -1478,18 +1509,22 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
             iax.loops[j].os = post ? ltsB[j] : los_user[j];
         }
         d.im = 0;
-        if (fuse_pre) emit_c2r_axis(p, N, &iax, in, rs, d, post ? tsB : os, pre);
-        else emit_c2r_axis(p, N, &iax, A, tsA, d, post ? tsB : os, 0);
+        if (fuse_pre) emit_c2r_axis(p, N, &iax, in, rs, d, post ? pimB : os, pre, post ? psB : 0, post ? pimB : 0);
+        else emit_c2r_axis(p, N, &iax, A, tsA, d, post ? pimB : os, 0, post ? psB : 0, post ? pimB : 0);
     } else {
         for (j = 0; j < nl; ++j) { iax.loops[j].is = ltsA[j]; iax.loops[j].os = ltsA[j]; }
         iax.n = N; iax.is = tsA; iax.os = tsA;
         iax.src = A; iax.dst = A;
         fa_emit_axis(p, &iax);
-        B = A; tsB = tsA;
+        B = A; tsB = tsA; unitB = 2;
         for (j = 0; j < nl; ++j) ltsB[j] = ltsA[j];
     }
 
-    if (post) emit_r2r_step(p, post, n, Kpost, twmod, B, tsB, out, os, axp, ltsB, los_user, 1);
+    if (post) {
+        fa_loc sB = B;
+        if (unitB == 1) sB.im = pimB;          /* real sequence read as pairs, see above */
+        emit_r2r_step(p, post, n, Kpost, twmod, sB, unitB == 1 ? psB : tsB, out, os, axp, ltsB, los_user, 1);
+    }
     if (abuf >= 0) buf_release(p, abuf);
     if (bbuf >= 0) buf_release(p, bbuf);
 }

@@ -399,6 +399,22 @@ class Interp(object):
             else:
                 dst[(doff + j * s.os_l)[mask]] = v[mask]
 
+        def SP(j, mask=None):
+            """real scratch sequence addressed as pairs: element j at (j >> 1) is_l + (j & 1) src_im"""
+            j = np.broadcast_to(j, full)
+            jj = j if mask is None else np.where(mask, j, 0)
+            v = src[soff + (jj >> 1) * s.is_l + (jj & 1) * s.src_im]
+            return v if mask is None else np.where(mask, v, 0.0)
+
+        def DP(j, v, mask=None):
+            j = np.broadcast_to(j, full)
+            v = np.broadcast_to(v, full)
+            addr = doff + (j >> 1) * s.os_l + (j & 1) * s.dst_im
+            if mask is None:
+                dst[addr] = v
+            else:
+                dst[addr[mask]] = v[mask]
+
         def DI(j, v):
             dst[doff + np.broadcast_to(j, full) * s.os_l + s.dst_im] = np.broadcast_to(v, full)
 
@@ -409,8 +425,8 @@ class Interp(object):
         elif mode in (fa.R2R_PRE_E10, fa.R2R_PRE_O10):
             has = 2 * k + 1 < n
             b = SR(2 * k + 1, has)
-            DR(k, SR(2 * k))
-            DR(n - 1 - k, -b if mode == fa.R2R_PRE_O10 else b, has)
+            DP(k, SR(2 * k))
+            DP(n - 1 - k, -b if mode == fa.R2R_PRE_O10 else b, has)
         elif mode in (fa.R2R_PRE_E01, fa.R2R_PRE_O01):
             if mode == fa.R2R_PRE_E01:
                 x, y = SR(k), SR(n - k, k > 0)
@@ -420,12 +436,12 @@ class Interp(object):
             v = w * (x - 1j * y)
             DR(k, v.real); DI(k, v.imag)
         elif mode == fa.R2R_PRE_E00:
-            DR(k, SR(np.where(k < n, k, 2 * (n - 1) - k)))
+            DP(k, SR(np.where(k < n, k, 2 * (n - 1) - k)))
         elif mode == fa.R2R_PRE_O00:
             N = 2 * (n + 1)
             a = SR(k - 1, (k >= 1) & (k <= n))
             b = SR(N - k - 1, k > n + 1)
-            DR(k, a - b)
+            DP(k, a - b)
         elif mode in (fa.R2R_PRE_E11, fa.R2R_PRE_O11):
             xr, xi = SR(2 * k), SR(n - 1 - 2 * k)
             if mode == fa.R2R_PRE_O11:
@@ -455,8 +471,8 @@ class Interp(object):
                 DR(k - 1, -2 * v.imag, mid)
         elif mode in (fa.R2R_POST_E01, fa.R2R_POST_O01):
             has = 2 * k + 1 < n
-            b = SR(n - 1 - k, has)
-            DR(2 * k, SR(k))
+            b = SP(n - 1 - k, has)
+            DR(2 * k, SP(k))
             DR(2 * k + 1, -b if mode == fa.R2R_POST_O01 else b, has)
         elif mode == fa.R2R_POST_E00:
             DR(k, SR(k))
