@@ -84,6 +84,8 @@ constexpr int fa_rr_q(int R_other, int T) { return (R_other * T + 255) / 256; }
 constexpr int fa_rr_tile(int R1, int R2) {
     if (fa_rr_small(R1, R2)) return FA_RR_SMALL_ELEMS / (R1 * R2);
     int T = 8192 / (R1 * R2);
+    /* two powers of two (512 = 32 x 16): exactly 32 elements per item in both stages */
+    if (((R1 & (R1 - 1)) == 0) && ((R2 & (R2 - 1)) == 0)) return T;
     while (T > 1 && (fa_rr_q(R2, T) * R1 > fa_rr_lim(R1, true) || fa_rr_q(R1, T) * R2 > fa_rr_lim(R2, false))) --T;
     return T;
 }
