@@ -9,7 +9,7 @@ LIBDIR := fftw3_amd/lib
 CFLAGS := -O2 -fPIC -std=gnu99 -Wall -Wextra -Iinclude -I$(CSRC)
 HIPFLAGS := -O3 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -std=c++17 -Wall
 
-OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/hostmath.o $(CSRC)/kernels.o $(CSRC)/kernels_rr.o
+OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/hostmath.o $(CSRC)/kernels.o $(CSRC)/kernels_rr.o $(CSRC)/kernels_r3.o
 
 all: $(LIBDIR)/libfftw3_amd.so
 

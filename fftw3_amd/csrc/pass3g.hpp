@@ -1,0 +1,205 @@
+/*
+ * pass3g.hpp -- register-resident three-stage pass for contiguous rows of a
+ * mixed-radix length L = R1 * R2 * R3 <= 4096 (1000 = 10 x 10 x 10, 1536 = 16 x 12 x 8,
+ * 3000 = 15 x 20 x 10, ...): the general form of pass3s.hpp (which keeps the tuned
+ * 8/16 x 16 x 16 kernels for 2048 / 4096).
+ *
+ * One workgroup of 256 work-items transforms T whole rows (T * L <= 8192):
+ *
+ *   A   l = a + M i     (M = R2 R3; butterfly g -> (t, a), a fastest)   DFT-R1 over i -> d1,
+ *                        times w_L^(a d1)
+ *   x1  image E1[t][d1][a]
+ *   B   a = a2 + R3 i2  (butterfly h -> (t, d1, a2), a2 fastest)         DFT-R2 over i2 -> d2,
+ *                        times w_M^(a2 d2) = w_L^(a2 d2 R1)
+ *   x2  image E2[t][d2][a2][d1]
+ *   C   (butterfly j -> (t, d2, d1), d1 fastest)                         DFT-R3 over a2 -> c
+ *       X[d1 + R1 d2 + R1 R2 c]
+ *
+ * Rows are contiguous on both sides: stage A's lanes read consecutive a, stage C's
+ * lanes write consecutive d1 + R1 d2 (runs of R1 R2 elements).
+ *
+ * There are no predicates: a work-item whose butterfly number lies beyond the tile (a
+ * partial last slot, or rows past the end of the batch) recomputes the LAST valid
+ * butterfly instead -- it loads the same data and stores the same values to the same
+ * places, which is harmless, and the straight-line code keeps every array in registers
+ * (a run-time `if` around the LDS traffic of passrr.hpp once cost 60-120 spilled VGPRs).
+ *
+ * Reference counterpart: nested Cooley-Tukey nodes inside one plan, e.g.
+ * (dft-ct-dit/10 (dftw-direct-10 "t1_10") (dft-ct-dit/10 ... (dft-direct-10 "n1_10")))
+ * for n = 1000 (fftw/fftw_api.c:2078-2202; codelets fftw/dft_scalar/codelets/t1_10.c, n1_10.c).
+ */
+#ifndef FA_PASS3G_HPP
+#define FA_PASS3G_HPP
+
+constexpr int fa_3g_q(int nb) { return (nb + 255) / 256; }
+/* rows per tile: as many as fit 8192 elements with at most 32 elements per item in every stage */
+constexpr int fa_3g_tile(int R1, int R2, int R3) {
+    const int L = R1 * R2 * R3;
+    int T = 8192 / L;
+    if (T < 1) T = 1;
+    while (T > 1 && (fa_3g_q(T * R2 * R3) * R1 > 32 || fa_3g_q(T * R1 * R3) * R2 > 32 ||
+                     fa_3g_q(T * R1 * R2) * R3 > 32)) --T;
+    return T;
+}
+
+template <int R1, int R2, int R3> struct P3GGeom {
+    static constexpr int L = R1 * R2 * R3;
+    static constexpr int M = R2 * R3;
+    static constexpr int T = fa_3g_tile(R1, R2, R3);
+    static constexpr int NBA = T * M, NBB = T * R1 * R3, NBC = T * R1 * R2;
+    static constexpr int QA = fa_3g_q(NBA), QB = fa_3g_q(NBB), QC = fa_3g_q(NBC);
+    static constexpr bool fits = QA * R1 <= 32 && QB * R2 <= 32 && QC * R3 <= 32;
+    static constexpr int S1 = M + (M % 2 == 0 ? 1 : 0);            /* E1 row stride, odd */
+    static constexpr int A2S = R1 + (R1 % 2 == 0 ? 1 : 0);         /* E2 stride of a2, odd */
+    static constexpr int SD2 = R3 * A2S + ((R3 * A2S) % 2 == 0 ? 1 : 0);
+    static constexpr int E1 = T * R1 * S1;
+    static constexpr int E2 = T * R2 * SD2;
+    static constexpr int lds_doubles = (E1 > E2 ? E1 : E2) + 16;
+};
+
+template <int R1, int R2, int R3>
+__global__ void __launch_bounds__(256, 2)
+pass3g_kernel(const P3SArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double plane[];
+    typedef P3GGeom<R1, R2, R3> G;
+    constexpr int M = G::M, T = G::T, QA = G::QA, QB = G::QB, QC = G::QC;
+    constexpr int S1 = G::S1, A2S = G::A2S, SD2 = G::SD2;
+    const int tid = threadIdx.x;
+
+    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
+    i64 tile = blk % a.ntiles;
+    i64 rest = blk / a.ntiles;
+    i64 soff = 0, doff = 0;
+    for (int d = 1; d < a.ndims; ++d) {
+        i64 idx = rest % a.dn[d];
+        rest /= a.dn[d];
+        soff += idx * a.dis[d];
+        doff += idx * a.dos[d];
+    }
+    const i64 t0 = tile * T;
+    const int Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
+    const double *src = a.src + soff + t0 * a.dis[0];
+    double *dst = a.dst + doff + t0 * a.dos[0];
+
+    /* ---- stage A */
+    cplx x[QA][R1];
+    int at[QA], aa[QA];
+#pragma unroll
+    for (int u = 0; u < QA; ++u) {
+        int g = u * 256 + tid;
+        const int last = Tcur * M - 1;
+        g = g < last ? g : last;                      /* beyond the tile: redo the last butterfly */
+        at[u] = g / M;
+        aa[u] = g - at[u] * M;
+        const double *p = src + (i64)at[u] * a.dis[0] + 2 * aa[u];
+#pragma unroll
+        for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + (i64)i * (2 * M));
+    }
+    if (a.flags & FFTW_AMD_F_SWAP_IN) {
+#pragma unroll
+        for (int u = 0; u < QA; ++u)
+#pragma unroll
+            for (int i = 0; i < R1; ++i) { double s = x[u][i].x; x[u][i].x = x[u][i].y; x[u][i].y = s; }
+    }
+#pragma unroll
+    for (int u = 0; u < QA; ++u) {
+        RB<R1>::run(x[u]);
+        cplx pw[RB<R1>::bits];
+#pragma unroll
+        for (int s = 0; s < RB<R1>::bits; ++s) pw[s] = a.wL[(aa[u] << s) % G::L];
+        TwTreeR<R1, RB<R1>::bits - 1, 0, false, true>::run(x[u], pw, c_make(1.0, 0.0));
+    }
+
+    /* ---- exchange 1 -> stage B owners (a2 fastest, then d1, then t) */
+    cplx y[QB][R2];
+    int ba2[QB], bd1[QB], bt[QB];
+#pragma unroll
+    for (int v = 0; v < QB; ++v) {
+        int h = v * 256 + tid;
+        const int last = Tcur * R1 * R3 - 1;
+        h = h < last ? h : last;
+        ba2[v] = h % R3;
+        bd1[v] = (h / R3) % R1;
+        bt[v] = h / (R3 * R1);
+    }
+#pragma unroll
+    for (int u = 0; u < QA; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[(at[u] * R1 + d) * S1 + aa[u]] = x[u][RB<R1>::slot(d)].x;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int i = 0; i < R2; ++i) y[v][i].x = plane[(bt[v] * R1 + bd1[v]) * S1 + ba2[v] + R3 * i];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < QA; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[(at[u] * R1 + d) * S1 + aa[u]] = x[u][RB<R1>::slot(d)].y;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int i = 0; i < R2; ++i) y[v][i].y = plane[(bt[v] * R1 + bd1[v]) * S1 + ba2[v] + R3 * i];
+    __syncthreads();
+
+    /* ---- stage B: DFT-R2 over i2, twiddle w_M^(a2 d2) = wL[a2 d2 R1] */
+#pragma unroll
+    for (int v = 0; v < QB; ++v) {
+        RB<R2>::run(y[v]);
+        cplx pw[RB<R2>::bits];
+#pragma unroll
+        for (int s = 0; s < RB<R2>::bits; ++s) pw[s] = a.wL[((ba2[v] << s) * R1) % G::L];
+        TwTreeR<R2, RB<R2>::bits - 1, 0, false, true>::run(y[v], pw, c_make(1.0, 0.0));
+    }
+
+    /* ---- exchange 2 -> stage C owners (d1 fastest, then d2, then t) */
+    cplx z[QC][R3];
+    int cd1[QC], cd2[QC], ct[QC];
+#pragma unroll
+    for (int w = 0; w < QC; ++w) {
+        int j = w * 256 + tid;
+        const int last = Tcur * R1 * R2 - 1;
+        j = j < last ? j : last;
+        cd1[w] = j % R1;
+        cd2[w] = (j / R1) % R2;
+        ct[w] = j / (R1 * R2);
+    }
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int d = 0; d < R2; ++d)
+            plane[(bt[v] * R2 + d) * SD2 + ba2[v] * A2S + bd1[v]] = y[v][RB<R2>::slot(d)].x;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < QC; ++w)
+#pragma unroll
+        for (int q = 0; q < R3; ++q) z[w][q].x = plane[(ct[w] * R2 + cd2[w]) * SD2 + q * A2S + cd1[w]];
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int d = 0; d < R2; ++d)
+            plane[(bt[v] * R2 + d) * SD2 + ba2[v] * A2S + bd1[v]] = y[v][RB<R2>::slot(d)].y;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < QC; ++w)
+#pragma unroll
+        for (int q = 0; q < R3; ++q) z[w][q].y = plane[(ct[w] * R2 + cd2[w]) * SD2 + q * A2S + cd1[w]];
+
+    /* ---- stage C: DFT-R3 over a2, store X[d1 + R1 d2 + R1 R2 c] */
+    const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
+#pragma unroll
+    for (int w = 0; w < QC; ++w) {
+        RB<R3>::run(z[w]);
+        double *p = dst + (i64)ct[w] * a.dos[0] + 2 * (cd1[w] + R1 * cd2[w]);
+#pragma unroll
+        for (int c = 0; c < R3; ++c) {
+            cplx v = z[w][RB<R3>::slot(c)];
+            if (sw) { double s = v.x; v.x = v.y; v.y = s; }
+            *reinterpret_cast<cplx *>(p + (i64)c * (2 * R1 * R2)) = v;
+        }
+    }
+}
+
+#endif /* FA_PASS3G_HPP */

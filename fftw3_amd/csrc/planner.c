@@ -450,9 +450,10 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
         if (L == 1024) {
             s->variant = FFTW_AMD_K_P1024;  /* register-resident radix-32x32, 8 sequences per tile */
             s->tile = 8;
-        } else if ((L == 2048 || L == 4096) && is_l == 2 && os_l == 2 && tw_n == 0 && s->tile_lo_n == 1) {
+        } else if (fa_hip_r3_tile((int)L) > 0 && is_l == 2 && os_l == 2 && tw_n == 0 && s->tile_lo_n == 1 &&
+                   (L == 2048 || L == 4096 || s->dim_n[0] * 2 >= fa_hip_r3_tile((int)L))) {
             s->variant = FFTW_AMD_K_R3;     /* three-stage register kernel, whole contiguous rows */
-            s->tile = (int)(8192 / L);
+            s->tile = fa_hip_r3_tile((int)L);
         } else if (fa_hip_rr_tile((int)L) > 0 && s->dim_n[0] * s->tile_lo_n * 4 >= fa_hip_rr_tile((int)L) &&
                    (s->tile_lo_n == 1 || (L & (L - 1)) == 0)) {
             s->variant = FFTW_AMD_K_RR;     /* two-stage register kernel */
@@ -778,7 +779,7 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     if (contiguous && ax.n > 1024 && (ax.n & (ax.n - 1)) == 0 && ax.nloops > 0 &&
         !getenv("FFTW_AMD_NO_TUNED")) {
         /* ... except contiguous rows of 2048 / 4096: the three-stage kernel does them in one */
-        int rows3s = (ax.n == 2048 || ax.n == 4096) && iabs(ax.is) == 2 && iabs(ax.os) == 2 &&
+        int rows3s = fa_hip_r3_tile((int)ax.n) > 0 && iabs(ax.is) == 2 && iabs(ax.os) == 2 &&
                      ax.src.im == 1 && ax.dst.im == 1 &&
                      !((ax.flags_in | ax.flags_out) & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT)) &&
                      !getenv("FFTW_AMD_NO_3S");
@@ -789,7 +790,11 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
        the copy rate) beat one pass of the LDS kernel (1.3-1.8 TB/s) whenever both halves of
        a balanced split have a register kernel -- measured n = 3000: 1.27 vs 2.4 TB/s */
     if (contiguous && ax.n > 1024 && ax.n <= lmax1 && (ax.n & (ax.n - 1)) != 0 && ax.nloops > 0 &&
-        !getenv("FFTW_AMD_NO_TUNED")) {
+        !getenv("FFTW_AMD_NO_TUNED") &&
+        /* ... unless the three-stage rows kernel does the whole length in one trip */
+        !(fa_hip_r3_tile((int)ax.n) > 0 && iabs(ax.is) == 2 && iabs(ax.os) == 2 && ax.src.im == 1 &&
+          ax.dst.im == 1 && !((ax.flags_in | ax.flags_out) & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT)) &&
+          !getenv("FFTW_AMD_NO_3S"))) {
         i64 l2[FA_MAXPASS];
         if (fa_factor_passes_pref(ax.n, 2, 1, 1024, l2, has_register_kernel) == 2 &&
             has_register_kernel(l2[0]) && has_register_kernel(l2[1]))

@@ -28,6 +28,17 @@ def menu():
 MENU = menu()
 
 
+def menu3():
+    out = []
+    with open(os.path.join(ROOT, "fftw3_amd", "csrc", "r3_menu.inc")) as f:
+        for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read()):
+            out.append(tuple(int(v) for v in m.groups()))
+    return out
+
+
+MENU3 = menu3()
+
+
 def _run(n, hm, stride, dist):
     import torch
     rng = np.random.default_rng(n + hm)
@@ -78,3 +89,23 @@ def test_three_pass_output_twiddle_and_last_pass_variants(L, r1, r2, monkeypatch
     p, e = _run(512 * L, 4, 1, 512 * L)
     assert "pass-%d/reg2" % L in p.sprint(), p.sprint()
     assert e <= TOL, (L, e)
+
+
+@pytest.mark.parametrize("L,r1,r2,r3", MENU3, ids=[str(m[0]) for m in MENU3])
+def test_three_stage_rows_kernel(L, r1, r2, r3):
+    """every three-stage rows kernel of r3_menu.inc: forward out of place with a ragged last
+    tile, backward in place (swap flags), against the oracle"""
+    import torch
+    assert r1 * r2 * r3 == L
+    hm = 37
+    p, e = _run(L, hm, 1, L)
+    assert "pass-%d/reg3" % L in p.sprint(), p.sprint()
+    assert e <= TOL, (L, e)
+    rng = np.random.default_rng(L)
+    x = crand(rng, hm * L)
+    xd = torch.from_numpy(x).cuda()
+    q = fa.plan_many_dft(1, [L], hm, xd, None, 1, L, xd, None, 1, L, fa.BACKWARD)
+    assert "pass-%d/reg3" % L in q.sprint()
+    q.execute()
+    q.sync()
+    assert aerror(xd.cpu().numpy(), oracle_dft(x, (L,), hm, sign=+1)) <= TOL, L
