@@ -936,6 +936,8 @@ static void launch_pass_variant(const PassArgs &pa, dim3 grid, size_t lds, hipSt
 /* kernels_rr.hip */
 int fa_launch_pass3g(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                      i64 cs, i64 cn, hipStream_t st);
+int fa_launch_pass3t(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                     i64 cs, i64 cn, hipStream_t st);
 int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                      i64 cs, i64 cn, hipStream_t st);
 int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
@@ -1051,7 +1053,8 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
     if (d->variant == FFTW_AMD_K_P1024 && launch_p1024(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_RR && fa_launch_passrr(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_R3 && (fa_launch_pass3s(d, bufs, tables, cs, cn, st) == 0 ||
-                                        fa_launch_pass3g(d, bufs, tables, cs, cn, st) == 0)) return 0;
+                                        fa_launch_pass3g(d, bufs, tables, cs, cn, st) == 0 ||
+                                        fa_launch_pass3t(d, bufs, tables, cs, cn, st) == 0)) return 0;
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
     for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {

@@ -77,3 +77,96 @@ int fa_launch_pass3g(const fftw_amd_step_desc *d, double *const *bufs, void *con
     }
     return 1;
 }
+
+/* ---- strided / transposed forms (pass3t_kernel), menu r3t_menu.inc ---------------- */
+
+template <int R1, int R2, int R3, bool IN_T, int TW>
+static void launch_3t_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    static_assert(P3TGeom<R1, R2, R3>::fits, "menu entry exceeds the per-item element budget");
+    const size_t lds = P3TGeom<R1, R2, R3>::lds_doubles * sizeof(double);
+    if (!attr_done) {
+        FA_CHECK(hipFuncSetAttribute((const void *)pass3t_kernel<R1, R2, R3, IN_T, TW>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pass3t_kernel<R1, R2, R3, IN_T, TW>), grid, dim3(256), lds, st, pa);
+}
+
+/* column passes (T,T) without / with output twiddle, transposed last passes (L,T) without /
+   with input twiddle; anything else goes to the LDS kernel */
+template <int R1, int R2, int R3>
+static int dispatch_3t(const P1024Args &pa, dim3 grid, hipStream_t st, bool in_t, bool out_t, int tw) {
+    if (in_t && out_t) {
+        if (tw == 0) { launch_3t_variant<R1, R2, R3, true, 0>(pa, grid, st); return 0; }
+        if (tw == 1) { launch_3t_variant<R1, R2, R3, true, 1>(pa, grid, st); return 0; }
+        return 1;
+    }
+    if (!in_t && out_t) {
+        if (tw == 0) { launch_3t_variant<R1, R2, R3, false, 0>(pa, grid, st); return 0; }
+        if (tw == 2) { launch_3t_variant<R1, R2, R3, false, 2>(pa, grid, st); return 0; }
+    }
+    return 1;
+}
+
+/* sequences per tile of the strided three-stage kernel for length L (0: none) */
+extern "C" int fa_hip_r3t_tile(int L) {
+    switch (L) {
+#define X(L_, R1_, R2_, R3_) case L_: return P3TGeom<R1_, R2_, R3_>::T;
+#include "r3t_menu.inc"
+#undef X
+    }
+    return 0;
+}
+
+int fa_launch_pass3t(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                     i64 cs, i64 cn, hipStream_t st) {
+    P1024Args pa;
+    int bd = d->batch_dim;
+    i64 sbase = d->src_base, dbase = d->dst_base;
+    const int T = fa_hip_r3t_tile(d->L);
+    if (T <= 0 || d->tile != T || d->src_im != 1 || d->dst_im != 1 || d->tile_lo_n > 1 ||
+        (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
+        return 1;
+    for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+        pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+        pa.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+        pa.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+        pa.dtw[i] = (i < d->ndims) ? d->dim_tw[i] : 0;
+    }
+    if (bd >= 0) {
+        sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+        dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+        pa.dn[bd] = cn;
+    }
+    pa.src = bufs[d->src_buf] + sbase;
+    pa.dst = bufs[d->dst_buf] + dbase;
+    pa.is_l = d->is_l;
+    pa.os_l = d->os_l;
+    if (((uintptr_t)pa.src % 16) || ((uintptr_t)pa.dst % 16) || (pa.is_l % 2) || (pa.os_l % 2)) return 1;
+    for (int i = 0; i < d->ndims; ++i)
+        if ((pa.dis[i] % 2) || (pa.dos[i] % 2)) return 1;
+    pa.w1024 = (const cplx *)tables[d->table];
+    pa.tw_shift = d->tw_shift;
+    pa.tw_lo = d->tw_n ? (const cplx *)tables[d->tw_lo] : NULL;
+    pa.tw_hi = d->tw_n ? (const cplx *)tables[d->tw_hi] : NULL;
+    pa.ndims = d->ndims;
+    pa.flags = d->flags;
+    pa.lo_sh = 0; pa.lo_is = 0; pa.lo_os = 0;
+    pa.ntiles = (pa.dn[0] + T - 1) / T;
+    i64 nblocks = pa.ntiles;
+    for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
+    if (nblocks <= 0) return 0;
+    if (nblocks > 0x7fffffffLL) return 1;
+    if (pa.dn[0] * 4 < T) return 1;              /* a mostly empty tile: the LDS kernel */
+    dim3 grid((unsigned)nblocks, 1, 1);
+    bool in_t = pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l);
+    bool out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);
+    int tw = d->tw_n == 0 ? 0 : ((d->flags & FFTW_AMD_F_TW_IN) ? 2 : 1);
+    switch (d->L) {
+#define X(L_, R1_, R2_, R3_) case L_: return dispatch_3t<R1_, R2_, R3_>(pa, grid, st, in_t, out_t, tw);
+#include "r3t_menu.inc"
+#undef X
+    }
+    return 1;
+}

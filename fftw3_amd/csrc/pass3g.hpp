@@ -202,4 +202,202 @@ pass3g_kernel(const P3SArgs a) {
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* The same three stages for the other positions of a plan (L <= 1024, tile   */
+/* of T = 8192 / L >= 8 sequences): column passes (sequences fastest on both  */
+/* sides, IN_T = OUT_T = true) without twiddle or with the inter-pass twiddle */
+/* on the output (HAS_TW = 1), and the last pass of a split (rows in,         */
+/* transposed store: IN_T = false, OUT_T = true) without twiddle or with it   */
+/* on the input (HAS_TW = 2).  Arguments are those of pass1024 (P1024Args).   */
+/* ------------------------------------------------------------------------ */
+template <int R1, int R2, int R3> struct P3TGeom {
+    static constexpr int L = R1 * R2 * R3;
+    static constexpr int M = R2 * R3;
+    static constexpr int T = 8192 / L;
+    static constexpr int NBA = T * M, NBB = T * R1 * R3, NBC = T * R1 * R2;
+    static constexpr int QA = fa_3g_q(NBA), QB = fa_3g_q(NBB), QC = fa_3g_q(NBC);
+    static constexpr bool fits = T >= 8 && QA * R1 <= 40 && QB * R2 <= 40 && QC * R3 <= 40;   /* the menu keeps only spill-free ones */
+    static constexpr int TP = T + 1;                               /* odd stride of t where it is not fastest */
+    /* column form: element (d1, a, t) at (d1 * M + a) * T + t, rows of d1 padded to stride = T mod 32 */
+    static constexpr int S1C = M * T + ((32 + T - (M * T) % 32) % 32);
+    static constexpr int S2C = R3 * R1 * T + ((32 + T - (R3 * R1 * T) % 32) % 32);
+    static constexpr int S1R = M + (M % 2 == 0 ? 1 : 0);           /* rows form: as P3GGeom */
+    static constexpr int E1 = (R1 * S1C > T * R1 * S1R ? R1 * S1C : T * R1 * S1R);
+    static constexpr int E2C = R2 * S2C;
+    static constexpr int E2R = R2 * R3 * R1 * TP;
+    static constexpr int lds_doubles = (E1 > (E2C > E2R ? E2C : E2R) ? E1 : (E2C > E2R ? E2C : E2R)) + 16;
+};
+
+template <int R1, int R2, int R3, bool IN_T, int HAS_TW>
+__global__ void __launch_bounds__(256, 2)
+pass3t_kernel(const P1024Args a) {
+    extern __shared__ __attribute__((aligned(16))) double plane[];
+    typedef P3TGeom<R1, R2, R3> G;
+    constexpr int M = G::M, T = G::T, QA = G::QA, QB = G::QB, QC = G::QC;
+    const int tid = threadIdx.x;
+
+    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
+    i64 tile = blk % a.ntiles;
+    i64 rest = blk / a.ntiles;
+    i64 soff = 0, doff = 0, twb = 0;
+    for (int d = 1; d < a.ndims; ++d) {
+        i64 idx = rest % a.dn[d];
+        rest /= a.dn[d];
+        soff += idx * a.dis[d];
+        doff += idx * a.dos[d];
+        twb += idx * a.dtw[d];
+    }
+    const i64 t0 = tile * T;
+    const int Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
+    const double *src = a.src + soff + t0 * a.dis[0];
+    double *dst = a.dst + doff + t0 * a.dos[0];
+    const i64 q0 = twb + t0 * a.dtw[0];
+
+    /* ---- stage A: butterfly g -> (t, a); t fastest for column loads, a fastest for rows */
+    cplx x[QA][R1];
+    int at[QA], aa[QA];
+#pragma unroll
+    for (int u = 0; u < QA; ++u) {
+        int g = u * 256 + tid;
+        g = g < G::NBA - 1 ? g : G::NBA - 1;
+        int t = IN_T ? g % T : g / M;
+        aa[u] = IN_T ? g / T : g % M;
+        t = t < Tcur - 1 ? t : Tcur - 1;              /* sequences past the end: redo the last one */
+        at[u] = t;
+        const double *p = src + (i64)aa[u] * a.is_l + (i64)t * a.dis[0];
+        const i64 step = (i64)M * a.is_l;
+#pragma unroll
+        for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + i * step);
+    }
+    if (a.flags & FFTW_AMD_F_SWAP_IN) {
+#pragma unroll
+        for (int u = 0; u < QA; ++u)
+#pragma unroll
+            for (int i = 0; i < R1; ++i) { double s = x[u][i].x; x[u][i].x = x[u][i].y; x[u][i].y = s; }
+    }
+#pragma unroll
+    for (int u = 0; u < QA; ++u) {
+        if (HAS_TW == 2) {
+            /* conj(w_N^((a + M i) q)) on the input */
+            const i64 q = q0 + (i64)at[u] * a.dtw[0];
+            cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * aa[u]);
+            cplx pw[RB<R1>::bits];
+#pragma unroll
+            for (int s = 0; s < RB<R1>::bits; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * M) << s);
+            TwTreeR<R1, RB<R1>::bits - 1, 0, true, false>::run(x[u], pw, base);
+        }
+        RB<R1>::run(x[u]);
+        cplx pw[RB<R1>::bits];
+#pragma unroll
+        for (int s = 0; s < RB<R1>::bits; ++s) pw[s] = a.w1024[(aa[u] << s) % G::L];
+        TwTreeR<R1, RB<R1>::bits - 1, 0, false, true>::run(x[u], pw, c_make(1.0, 0.0));
+    }
+
+    /* ---- exchange 1.  Column form: E1[d1][a][t]; rows form: E1[t][d1][a].  Stage B owners:
+       column form (t, a2, d1) with t fastest; rows form (d1, a2, t) with d1 fastest. */
+    cplx y[QB][R2];
+    int ba2[QB], bd1[QB], bt[QB];
+#pragma unroll
+    for (int v = 0; v < QB; ++v) {
+        int h = v * 256 + tid;
+        h = h < G::NBB - 1 ? h : G::NBB - 1;
+        if (IN_T) { bt[v] = h % T; ba2[v] = (h / T) % R3; bd1[v] = h / (T * R3); }
+        else      { bd1[v] = h % R1; ba2[v] = (h / R1) % R3; bt[v] = h / (R1 * R3); }
+        bt[v] = bt[v] < Tcur - 1 ? bt[v] : Tcur - 1;
+    }
+#define FA_E1(t, d1, a_) (IN_T ? ((d1) * G::S1C + (a_) * T + (t)) : (((t) * R1 + (d1)) * G::S1R + (a_)))
+#pragma unroll
+    for (int u = 0; u < QA; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[FA_E1(at[u], d, aa[u])] = x[u][RB<R1>::slot(d)].x;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int i = 0; i < R2; ++i) y[v][i].x = plane[FA_E1(bt[v], bd1[v], ba2[v] + R3 * i)];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < QA; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[FA_E1(at[u], d, aa[u])] = x[u][RB<R1>::slot(d)].y;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int i = 0; i < R2; ++i) y[v][i].y = plane[FA_E1(bt[v], bd1[v], ba2[v] + R3 * i)];
+    __syncthreads();
+#undef FA_E1
+
+    /* ---- stage B: DFT-R2 over i2, twiddle w_M^(a2 d2) = wL[a2 d2 R1] */
+#pragma unroll
+    for (int v = 0; v < QB; ++v) {
+        RB<R2>::run(y[v]);
+        cplx pw[RB<R2>::bits];
+#pragma unroll
+        for (int s = 0; s < RB<R2>::bits; ++s) pw[s] = a.w1024[((ba2[v] << s) * R1) % G::L];
+        TwTreeR<R2, RB<R2>::bits - 1, 0, false, true>::run(y[v], pw, c_make(1.0, 0.0));
+    }
+
+    /* ---- exchange 2 -> stage C owners (t fastest, then d1, then d2): transposed / column store.
+       Column form: E2[d2][a2][d1][t]; rows form: the same with t padded to an odd stride. */
+    cplx z[QC][R3];
+    int cd1[QC], cd2[QC], ct[QC];
+#pragma unroll
+    for (int w = 0; w < QC; ++w) {
+        int j = w * 256 + tid;
+        j = j < G::NBC - 1 ? j : G::NBC - 1;
+        ct[w] = j % T;
+        ct[w] = ct[w] < Tcur - 1 ? ct[w] : Tcur - 1;
+        cd1[w] = (j / T) % R1;
+        cd2[w] = j / (T * R1);
+    }
+#define FA_E2(t, d2, a2, d1) (IN_T ? ((d2) * G::S2C + ((a2) * R1 + (d1)) * T + (t)) \
+                                   : ((((d2) * R3 + (a2)) * R1 + (d1)) * G::TP + (t)))
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int d = 0; d < R2; ++d) plane[FA_E2(bt[v], d, ba2[v], bd1[v])] = y[v][RB<R2>::slot(d)].x;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < QC; ++w)
+#pragma unroll
+        for (int q = 0; q < R3; ++q) z[w][q].x = plane[FA_E2(ct[w], cd2[w], q, cd1[w])];
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int d = 0; d < R2; ++d) plane[FA_E2(bt[v], d, ba2[v], bd1[v])] = y[v][RB<R2>::slot(d)].y;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < QC; ++w)
+#pragma unroll
+        for (int q = 0; q < R3; ++q) z[w][q].y = plane[FA_E2(ct[w], cd2[w], q, cd1[w])];
+#undef FA_E2
+
+    /* ---- stage C: DFT-R3 over a2, optional output twiddle, store X[d1 + R1 d2 + R1 R2 c] */
+    const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
+#pragma unroll
+    for (int w = 0; w < QC; ++w) {
+        RB<R3>::run(z[w]);
+        const int tc = ct[w];
+        const int kb = cd1[w] + R1 * cd2[w];
+        if (HAS_TW == 1) {
+            const i64 q = q0 + (i64)tc * a.dtw[0];
+            cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * kb);
+            cplx pw[RB<R3>::bits];
+#pragma unroll
+            for (int s = 0; s < RB<R3>::bits; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * (R1 * R2)) << s);
+            TwTreeR<R3, RB<R3>::bits - 1, 0, true, true>::run(z[w], pw, base);
+        }
+        double *p = dst + (i64)kb * a.os_l + (i64)tc * a.dos[0];
+        const i64 step = (i64)(R1 * R2) * a.os_l;
+#pragma unroll
+        for (int c = 0; c < R3; ++c) {
+            cplx v = z[w][RB<R3>::slot(c)];
+            if (sw) { double s = v.x; v.x = v.y; v.y = s; }
+            *reinterpret_cast<cplx *>(p + c * step) = v;
+        }
+    }
+}
+
 #endif /* FA_PASS3G_HPP */

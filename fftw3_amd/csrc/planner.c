@@ -458,6 +458,9 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
                    (s->tile_lo_n == 1 || (L & (L - 1)) == 0)) {
             s->variant = FFTW_AMD_K_RR;     /* two-stage register kernel */
             s->tile = fa_hip_rr_tile((int)L);
+        } else if (fa_hip_r3t_tile((int)L) > 0 && s->tile_lo_n == 1 && s->dim_n[0] * 4 >= fa_hip_r3t_tile((int)L)) {
+            s->variant = FFTW_AMD_K_R3;     /* three-stage register kernel, column / transposed form */
+            s->tile = fa_hip_r3t_tile((int)L);
         }
     }
     s->tw_n = tw_n;
@@ -751,7 +754,7 @@ static void emit_rader(plan *p, const fa_axis *ax) {
 
 /* lengths with a register kernel (pass1024 / passrr) */
 static int has_register_kernel(i64 L) {
-    return L == 1024 || (L <= 1024 && fa_hip_rr_tile((int)L) > 0);
+    return L == 1024 || (L <= 1024 && (fa_hip_rr_tile((int)L) > 0 || fa_hip_r3t_tile((int)L) > 0));
 }
 
 static void fa_emit_axis(plan *p, const fa_axis *ax_in) {

@@ -39,6 +39,17 @@ def menu3():
 MENU3 = menu3()
 
 
+def menu3t():
+    out = []
+    with open(os.path.join(ROOT, "fftw3_amd", "csrc", "r3t_menu.inc")) as f:
+        for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read()):
+            out.append(tuple(int(v) for v in m.groups()))
+    return out
+
+
+MENU3T = menu3t()
+
+
 def _run(n, hm, stride, dist):
     import torch
     rng = np.random.default_rng(n + hm)
@@ -109,3 +120,25 @@ def test_three_stage_rows_kernel(L, r1, r2, r3):
     q.execute()
     q.sync()
     assert aerror(xd.cpu().numpy(), oracle_dft(x, (L,), hm, sign=+1)) <= TOL, L
+
+
+@pytest.mark.parametrize("L,r1,r2,r3", MENU3T, ids=[str(m[0]) for m in MENU3T])
+def test_three_stage_strided_forms(L, r1, r2, r3, monkeypatch):
+    """every strided three-stage kernel of r3t_menu.inc in the four forms the planner emits:
+    (T,T,0) single column pass and first pass of L x L, (L,T,2) its second pass,
+    (T,T,1) x2 in a forced L x L x 8 split, (L,T,0) as the last pass of 64 x 8 x L"""
+    assert r1 * r2 * r3 == L
+    p, e = _run(L, 300, 300, 1)                       # interleaved batch: one column pass
+    assert "pass-%d/reg3" % L in p.sprint(), p.sprint()
+    assert e <= TOL, (L, e)
+    p, e = _run(L * L, 3, 1, L * L)
+    assert p.sprint().count("pass-%d/reg3" % L) == 2, p.sprint()
+    assert e <= TOL, (L, e)
+    monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "%d,%d,8" % (L, L))
+    p, e = _run(L * L * 8, 1, 1, L * L * 8)
+    assert p.sprint().count("pass-%d/reg3" % L) == 2, p.sprint()
+    assert e <= TOL, (L, e)
+    monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "64,8,%d" % L)
+    p, e = _run(512 * L, 4, 1, 512 * L)
+    assert "pass-%d/reg3" % L in p.sprint(), p.sprint()
+    assert e <= TOL, (L, e)
