@@ -367,3 +367,47 @@ def test_planning_from_many_threads():
     for t in th:
         t.join()
     assert not errs, errs[:5]
+
+
+C_CLIENT = r"""
+/* a stock FFTW client: nothing here knows about the GPU library */
+#include <stdio.h>
+#include <fftw3.h>
+int main(void) {
+    int n = 1024, ok = 1;
+    fftw_complex *in = fftw_alloc_complex(n), *out = fftw_alloc_complex(n);
+    double *r = fftw_alloc_real(n);
+    fftw_plan p, q, t;
+    fftw_r2r_kind k = FFTW_REDFT10;
+    if (!in || !out || !r) return 2;
+    p = fftw_plan_dft_1d(n, in, out, FFTW_FORWARD, FFTW_ESTIMATE);
+    q = fftw_plan_dft_r2c_1d(n, r, out, FFTW_ESTIMATE);
+    t = fftw_plan_r2r_1d(n, r, r, k, FFTW_ESTIMATE);
+    ok = p && q && t && fftw_plan_dft_1d(0, in, out, FFTW_FORWARD, FFTW_ESTIMATE) == NULL;
+    {
+        double add, mul, fma;
+        fftw_flops(p, &add, &mul, &fma);
+        ok = ok && add + mul + 2 * fma > 0;
+        fftw_print_plan(t);
+        printf("\n");
+    }
+    fftw_destroy_plan(p); fftw_destroy_plan(q); fftw_destroy_plan(t);
+    fftw_free(in); fftw_free(out); fftw_free(r);
+    fftw_cleanup();
+    printf(ok ? "client ok\n" : "client FAILED\n");
+    return ok ? 0 : 1;
+}
+"""
+
+
+def test_stock_c_client_compiles_and_links_as_libfftw3(tmp_path):
+    """drop-in boundary: a plain FFTW program builds against include/fftw3.h and links with
+    -lfftw3 from fftw3_amd/lib (planning only here: no GPU in this tier)"""
+    src = tmp_path / "client.c"
+    exe = tmp_path / "client"
+    src.write_text(C_CLIENT)
+    libdir = os.path.join(ROOT, "fftw3_amd", "lib")
+    subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-L", libdir, "-lfftw3", "-Wl,-rpath," + libdir, "-lm", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and "client ok" in r.stdout and "rdft-r2r" in r.stdout, r.stdout
