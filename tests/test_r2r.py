@@ -502,3 +502,28 @@ def test_gpu_r2r_reference_verifier():
             p.sync()
             return dy.cpu().numpy().reshape((v,) + tuple(shape))
         V.verify_r2r(apply, shape, kinds, vecn=2, rounds=3)
+
+
+@pytest.mark.gpu
+def test_gpu_r2r_measure_mode_and_wisdom():
+    """FFTW_MEASURE on an r2r problem times the candidate configurations, records wisdom keyed
+    by the kinds, and the measured plan is still correct"""
+    import torch
+    rng = np.random.default_rng(33)
+    n, hm = 1 << 14, 64
+    x = rrand(rng, hm * n)
+    fa.forget_wisdom()
+    dx = _dev(x)
+    dy = torch.zeros_like(dx)
+    p = fa.plan_many_r2r(1, [n], hm, dx, None, 1, n, dy, None, 1, n, [fa.RODFT10], fa.MEASURE)
+    w = fa.export_wisdom_to_string()
+    assert "k9." in w, w                      # the wisdom key carries the r2r kind
+    dx.copy_(torch.from_numpy(x))             # MEASURE overwrote the arrays
+    p.execute()
+    p.sync()
+    assert aerror(dy.cpu().numpy(), oracle_r2r(x, [n], [fa.RODFT10], howmany=hm)) <= TOL
+    q = fa.plan_many_r2r(1, [n], hm, dx, None, 1, n, dy, None, 1, n, [fa.RODFT10], fa.WISDOM_ONLY)
+    q.execute()
+    q.sync()
+    assert aerror(dy.cpu().numpy(), oracle_r2r(x, [n], [fa.RODFT10], howmany=hm)) <= TOL
+    fa.forget_wisdom()
