@@ -9,6 +9,7 @@
 #include "passrr.hpp"
 #include "pass3s.hpp"
 #include "pass3g.hpp"
+#include "r2crows.hpp"
 
 template <int R1, int R2, int R3>
 static void launch_3g(const P3SArgs &pa, dim3 grid, hipStream_t st) {
@@ -169,4 +170,85 @@ int fa_launch_pass3t(const fftw_amd_step_desc *d, double *const *bufs, void *con
 #undef X
     }
     return 1;
+}
+
+/* ---- fused real rows -> half spectra (r2crows.hpp) ------------------------------- */
+
+template <int R1, int R2>
+static void launch_r2cr(const R2CRArgs &ra, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    const size_t lds = R2CRGeom<R1, R2>::lds_doubles * sizeof(double);
+    if (!attr_done) {
+        FA_CHECK(hipFuncSetAttribute((const void *)r2crows_kernel<R1, R2>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((r2crows_kernel<R1, R2>), grid, dim3(256), lds, st, ra);
+}
+
+extern "C" int fa_hip_r2c_rows_tile(int L) {
+    switch (L) {
+    case 64: return R2CRGeom<8, 8>::T;
+    case 128: return R2CRGeom<16, 8>::T;
+    case 256: return R2CRGeom<16, 16>::T;
+    case 512: return R2CRGeom<32, 16>::T;
+    case 1024: return R2CRGeom<32, 32>::T;
+    }
+    return 0;
+}
+
+/* A step with FFTW_AMD_F_R2C_ROWS has no other executor: the planner only emits it for
+   layouts this kernel takes (r2c_rows_layout_ok), so anything else here is a caller error
+   (new-array execution with differently aligned arrays) and fails loudly. */
+int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                      i64 cs, i64 cn, hipStream_t st) {
+    R2CRArgs ra;
+    int bd = d->batch_dim;
+    i64 sbase = d->src_base, dbase = d->dst_base;
+    const int T = fa_hip_r2c_rows_tile(d->L);
+    if (T <= 0 || d->tile != T || d->src_im != 1 || d->dst_im != 1 || d->is_l != 2 || d->os_l != 2) {
+        fprintf(stderr, "fftw3_amd: internal error: fused r2c rows step with an unsupported layout\n");
+        abort();
+    }
+    for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+        ra.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+        ra.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+        ra.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+    }
+    if (bd >= 0) {
+        sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+        dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+        ra.dn[bd] = cn;
+    }
+    ra.src = bufs[d->src_buf] + sbase;
+    ra.dst = bufs[d->dst_buf] + dbase;
+    if (((uintptr_t)ra.src % 16) || ((uintptr_t)ra.dst % 16)) {
+        fprintf(stderr, "fftw3_amd: fftw_execute_dft_r2c needs arrays aligned like the ones the plan was "
+                        "created with (16 bytes)\n");
+        abort();
+    }
+    ra.wL = (const cplx *)tables[d->table];
+    ra.tw_lo = (const cplx *)tables[d->tw_lo];
+    ra.tw_hi = (const cplx *)tables[d->tw_hi];
+    ra.tw_shift = d->tw_shift;
+    ra.ndims = d->ndims;
+    ra.ntiles = (ra.dn[0] + T - 1) / T;
+    i64 nblocks = ra.ntiles;
+    for (int i = 1; i < d->ndims; ++i) nblocks *= ra.dn[i];
+    if (nblocks <= 0) return 0;
+    dim3 grid;
+    if (nblocks <= 0x7fffffffLL) grid = dim3((unsigned)nblocks, 1, 1);
+    else {
+        unsigned gy = (unsigned)((nblocks + 0x3fffffffLL) / 0x40000000LL);
+        while (nblocks % gy) ++gy;
+        grid = dim3((unsigned)(nblocks / gy), gy, 1);
+    }
+    switch (d->L) {
+    case 64: launch_r2cr<8, 8>(ra, grid, st); break;
+    case 128: launch_r2cr<16, 8>(ra, grid, st); break;
+    case 256: launch_r2cr<16, 16>(ra, grid, st); break;
+    case 512: launch_r2cr<32, 16>(ra, grid, st); break;
+    case 1024: launch_r2cr<32, 32>(ra, grid, st); break;
+    }
+    return 0;
 }

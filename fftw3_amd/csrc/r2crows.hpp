@@ -1,0 +1,162 @@
+/*
+ * r2crows.hpp -- real rows to half spectra in ONE trip: the half-length complex DFT of
+ * the pair sequence z[j] = x[2j] + i x[2j+1] (two register stages, as passrr.hpp) and the
+ * r2c untangle, fused through the LDS.  For contiguous real rows of n = 2L, L = R1 R2 in
+ * {64, 128, 256, 512, 1024}: the last dimension of 2-D / 3-D real transforms and batched
+ * 1-D ones (256^3, 512^3, 1024^2 ...), which otherwise cost a pass plus an untangle trip.
+ *
+ * A workgroup of 256 items owns T = 4096 / L rows (16 complex elements per item):
+ *   A   l = a + R2 i   butterfly g -> (t, a), a fastest     DFT-R1 over i -> d, times w_L^(a d)
+ *   x   image E[t][d][a]  (one real plane at a time)
+ *   B   butterfly j -> (t, d), d fastest                    DFT-R2 over a -> c,  Z[d + R1 c]
+ *   u   Z goes to two LDS planes [t][k]; then one item per Hermitian pair (k, L - k):
+ *       Y[k] = E + w_n^k O,  Y[L-k] = conj(E - w_n^k O),  E = (Z[k] + conj Z[L-k]) / 2,
+ *       O = -i (Z[k] - conj Z[L-k]) / 2     (r2c_post_kernel in kernels.hip)
+ * No predicates: out-of-range butterflies / rows redo the last valid one (pass3g.hpp).
+ *
+ * Reference counterpart: rdft2 plans whose child is a complex DFT over the (r0, r1) pairs
+ * followed by the hc2cfdft codelet (ct_hc2c, fftw/fftw_api.c:5661-5845) -- executed there
+ * as two sweeps over the row as well.
+ */
+#ifndef FA_R2CROWS_HPP
+#define FA_R2CROWS_HPP
+
+template <int R1, int R2> struct R2CRGeom {
+    static constexpr int L = R1 * R2;
+    static constexpr int T = (4096 / L) > 0 ? (4096 / L) : 1;
+    static constexpr int NBA = T * R2, NBB = T * R1;
+    static constexpr int QA = (NBA + 255) / 256, QB = (NBB + 255) / 256;
+    static constexpr int SA = R2 + (R2 % 2 == 0 ? 1 : 0);          /* E: stride of d, odd */
+    static constexpr int ST = R1 * SA + ((R1 * SA) % 2 == 0 ? 1 : 0);
+    static constexpr int SX = L + 1;                               /* Z planes: row stride */
+    static constexpr int EX = T * ST;
+    static constexpr int lds_doubles = (EX > 2 * T * SX ? EX : 2 * T * SX) + 16;
+};
+
+struct R2CRArgs {
+    const double *src;      /* real rows: row t at src + t * dis[0] (+ loops), unit stride */
+    double *dst;            /* complex rows of L + 1 entries, unit stride (2 doubles) */
+    i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
+    const cplx *wL;         /* w_L^m */
+    const cplx *tw_lo;      /* two-level table of w_n^m, n = 2L */
+    const cplx *tw_hi;
+    i64 ntiles;
+    int tw_shift;
+    int ndims;
+};
+
+template <int R1, int R2>
+__global__ void __launch_bounds__(256, 2)
+r2crows_kernel(const R2CRArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double plane[];
+    typedef R2CRGeom<R1, R2> G;
+    constexpr int L = G::L, T = G::T, QA = G::QA, QB = G::QB, SA = G::SA, ST = G::ST, SX = G::SX;
+    const int tid = threadIdx.x;
+
+    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
+    i64 tile = blk % a.ntiles;
+    i64 rest = blk / a.ntiles;
+    i64 soff = 0, doff = 0;
+    for (int d = 1; d < a.ndims; ++d) {
+        i64 idx = rest % a.dn[d];
+        rest /= a.dn[d];
+        soff += idx * a.dis[d];
+        doff += idx * a.dos[d];
+    }
+    const i64 t0 = tile * T;
+    const int Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
+    const double *src = a.src + soff + t0 * a.dis[0];
+    double *dst = a.dst + doff + t0 * a.dos[0];
+
+    /* ---- stage A */
+    cplx x[QA][R1];
+    int at[QA], aa[QA];
+#pragma unroll
+    for (int u = 0; u < QA; ++u) {
+        int g = u * 256 + tid;
+        const int last = Tcur * R2 - 1;
+        g = g < last ? g : last;
+        at[u] = g / R2;
+        aa[u] = g - at[u] * R2;
+        const double *p = src + (i64)at[u] * a.dis[0] + 2 * aa[u];
+#pragma unroll
+        for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + (i64)i * (2 * R2));
+    }
+#pragma unroll
+    for (int u = 0; u < QA; ++u) {
+        RB<R1>::run(x[u]);
+        cplx pw[RB<R1>::bits];
+#pragma unroll
+        for (int s = 0; s < RB<R1>::bits; ++s) pw[s] = a.wL[(aa[u] << s) % L];
+        TwTreeR<R1, RB<R1>::bits - 1, 0, false, true>::run(x[u], pw, c_make(1.0, 0.0));
+    }
+
+    /* ---- exchange -> stage B owners (d fastest, then t) */
+    cplx y[QB][R2];
+    int bd[QB], bt[QB];
+#pragma unroll
+    for (int v = 0; v < QB; ++v) {
+        int j = v * 256 + tid;
+        const int last = Tcur * R1 - 1;
+        j = j < last ? j : last;
+        bt[v] = j / R1;
+        bd[v] = j - bt[v] * R1;
+    }
+#pragma unroll
+    for (int u = 0; u < QA; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[at[u] * ST + d * SA + aa[u]] = x[u][RB<R1>::slot(d)].x;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int q = 0; q < R2; ++q) y[v][q].x = plane[bt[v] * ST + bd[v] * SA + q];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < QA; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[at[u] * ST + d * SA + aa[u]] = x[u][RB<R1>::slot(d)].y;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int q = 0; q < R2; ++q) y[v][q].y = plane[bt[v] * ST + bd[v] * SA + q];
+    __syncthreads();
+
+    /* ---- stage B, then Z[t][d + R1 c] into the two planes */
+    double *zr = plane, *zi = plane + T * SX;
+#pragma unroll
+    for (int v = 0; v < QB; ++v) {
+        RB<R2>::run(y[v]);
+#pragma unroll
+        for (int c = 0; c < R2; ++c) {
+            const cplx w = y[v][RB<R2>::slot(c)];
+            zr[bt[v] * SX + bd[v] + R1 * c] = w.x;
+            zi[bt[v] * SX + bd[v] + R1 * c] = w.y;
+        }
+    }
+    __syncthreads();
+
+    /* ---- untangle: one item per pair (k, L - k) of a row, k fastest */
+    constexpr int NP = L / 2 + 1;
+    const int items = Tcur * NP;
+    for (int i = tid; i < items; i += 256) {
+        const int t = i / NP, k = i - t * NP;
+        const int km = L - k;
+        const int kr = (km == L) ? 0 : km;
+        const double ar = zr[t * SX + k], ai = zi[t * SX + k];
+        const double br = zr[t * SX + kr], bi = zi[t * SX + kr];
+        const double er = 0.5 * (ar + br), ei = 0.5 * (ai - bi);
+        const double dr = 0.5 * (ar - br), di = 0.5 * (ai + bi);
+        const cplx o = c_make(di, -dr);                         /* -i D */
+        const cplx p = c_mulc(o, tw2(a.tw_lo, a.tw_hi, a.tw_shift, k));
+        cplx yk = c_make(er + p.x, ei + p.y);
+        cplx ym = c_make(er - p.x, -(ei - p.y));
+        if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+        double *row = dst + (i64)t * a.dos[0];
+        *reinterpret_cast<cplx *>(row + 2 * k) = yk;
+        if (km != k) *reinterpret_cast<cplx *>(row + 2 * km) = ym;
+    }
+}
+
+#endif /* FA_R2CROWS_HPP */

@@ -137,7 +137,20 @@ class Interp(object):
                 m = l * twb
                 assert m.max() < s.tw_n
                 y = y * np.conj(self.tw2(s, m))
-            _store(dst, doff, s.dst_im, s.flags, y)
+            if s.flags & fa.F_R2C_ROWS:
+                # fused r2c untangle for n = 2L: L + 1 outputs per row at stride os_l
+                zm = np.conj(np.roll(y[::-1], 1, axis=0))            # conj Z[(L - k) % L]
+                k = np.arange(L, dtype=np.int64).reshape([L] + [1] * len(dn))
+                E = 0.5 * (y + zm)
+                O = -0.5j * (y - zm)
+                Y = E + O * np.conj(self.tw2(s, k))
+                Y[0] = Y[0].real
+                nyq = (y[0].real - y[0].imag) + 0j                   # Y[L] = Re Z[0] - Im Z[0]
+                dbase_off = doff - l * s.os_l                        # offset of entry 0 of every row
+                _store(dst, dbase_off + l * s.os_l, s.dst_im, s.flags, Y)
+                _store(dst, (dbase_off + L * s.os_l)[0:1], s.dst_im, s.flags, nyq[None])
+            else:
+                _store(dst, doff, s.dst_im, s.flags, y)
         elif s.kind in (fa.STEP_COPY, fa.STEP_HERM_EXPAND):
             K = s.aux_n
             g = _grids([K] + dn)
