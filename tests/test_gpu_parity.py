@@ -578,3 +578,32 @@ def test_stock_c_client_runs_on_the_gpu(torch_dev, tmp_path):
                     "-lfftw3", "-Wl,-rpath," + libdir, "-lm", "-o", str(exe)], check=True)
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "client ok" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("n", [128, 256, 512, 1024, 2048])
+def test_fused_real_rows_kernel(torch_dev, n):
+    """r2c of contiguous rows of 128 ... 2048 reals runs as ONE fused step (pass + untangle):
+    batched 1-D with a ragged last tile, and as the last dimension of 2-D / 3-D transforms"""
+    from util import oracle_r2c, rrand
+    torch, dev = torch_dev
+    rng = np.random.default_rng(n)
+    hm = 37
+    x = rrand(rng, hm, n)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.zeros((hm, n // 2 + 1), dtype=torch.complex128, device=dev)
+    p = fa.plan_many_dft_r2c(1, [n], hm, xd, None, 1, n, yd, None, 1, n // 2 + 1)
+    assert "r2c-rows" in p.sprint() and "untangle" not in p.sprint(), p.sprint()
+    p.execute()
+    torch.cuda.synchronize()
+    assert aerror(yd.cpu().numpy(), oracle_r2c(x, (n,), hm).reshape(hm, n // 2 + 1)) < TOL
+    for shape in ((12, n), (3, 10, n)):
+        size = int(np.prod(shape))
+        hs = size // n * (n // 2 + 1)
+        x = rrand(rng, 2, size)
+        xd = torch.from_numpy(x).to(dev)
+        yd = torch.zeros((2, hs), dtype=torch.complex128, device=dev)
+        p = fa.plan_many_dft_r2c(len(shape), list(shape), 2, xd, None, 1, size, yd, None, 1, hs)
+        assert "r2c-rows" in p.sprint(), p.sprint()
+        p.execute()
+        torch.cuda.synchronize()
+        assert aerror(yd.cpu().numpy(), oracle_r2c(x, shape, 2).reshape(2, hs)) < TOL, shape
