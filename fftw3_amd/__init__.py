@@ -55,6 +55,7 @@ R2HC, HC2R, DHT, REDFT00, REDFT01, REDFT10, REDFT11, RODFT00, RODFT01, RODFT10, 
 F_SWAP_IN, F_SWAP_OUT, F_REAL_IN, F_REAL_OUT = 1, 2, 4, 8
 F_MUL_TABLE, F_MUL_CONJ, F_PERM_SRC, F_PERM_DST, F_CONJ_OUT, F_TW_IN = 16, 32, 64, 128, 256, 512
 F_R2C_ROWS = 1024
+F_C2R_ROWS = 2048
 
 
 class StepDesc(C.Structure):

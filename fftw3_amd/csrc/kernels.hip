@@ -1052,7 +1052,7 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
 static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                        i64 cs, i64 cn, hipStream_t st) {
     PassArgs pa;
-    if (d->flags & FFTW_AMD_F_R2C_ROWS) return fa_launch_r2crows(d, bufs, tables, cs, cn, st);
+    if (d->flags & (FFTW_AMD_F_R2C_ROWS | FFTW_AMD_F_C2R_ROWS)) return fa_launch_r2crows(d, bufs, tables, cs, cn, st);
     if (d->variant == FFTW_AMD_K_P1024 && launch_p1024(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_RR && fa_launch_passrr(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_R3 && (fa_launch_pass3s(d, bufs, tables, cs, cn, st) == 0 ||

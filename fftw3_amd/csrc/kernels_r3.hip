@@ -175,15 +175,18 @@ int fa_launch_pass3t(const fftw_amd_step_desc *d, double *const *bufs, void *con
 /* ---- fused real rows -> half spectra (r2crows.hpp) ------------------------------- */
 
 template <int R1, int R2>
-static void launch_r2cr(const R2CRArgs &ra, dim3 grid, hipStream_t st) {
+static void launch_r2cr(const R2CRArgs &ra, dim3 grid, hipStream_t st, bool inverse) {
     static bool attr_done = false;
     const size_t lds = R2CRGeom<R1, R2>::lds_doubles * sizeof(double);
     if (!attr_done) {
         FA_CHECK(hipFuncSetAttribute((const void *)r2crows_kernel<R1, R2>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FA_CHECK(hipFuncSetAttribute((const void *)c2rrows_kernel<R1, R2>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((r2crows_kernel<R1, R2>), grid, dim3(256), lds, st, ra);
+    if (inverse) hipLaunchKernelGGL((c2rrows_kernel<R1, R2>), grid, dim3(256), lds, st, ra);
+    else hipLaunchKernelGGL((r2crows_kernel<R1, R2>), grid, dim3(256), lds, st, ra);
 }
 
 extern "C" int fa_hip_r2c_rows_tile(int L) {
@@ -197,7 +200,7 @@ extern "C" int fa_hip_r2c_rows_tile(int L) {
     return 0;
 }
 
-/* A step with FFTW_AMD_F_R2C_ROWS has no other executor: the planner only emits it for
+/* A step with FFTW_AMD_F_R2C_ROWS / FFTW_AMD_F_C2R_ROWS has no other executor: the planner only emits it for
    layouts this kernel takes (r2c_rows_layout_ok), so anything else here is a caller error
    (new-array execution with differently aligned arrays) and fails loudly. */
 int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
@@ -243,12 +246,13 @@ int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *co
         while (nblocks % gy) ++gy;
         grid = dim3((unsigned)(nblocks / gy), gy, 1);
     }
+    const bool inverse = (d->flags & FFTW_AMD_F_C2R_ROWS) != 0;
     switch (d->L) {
-    case 64: launch_r2cr<8, 8>(ra, grid, st); break;
-    case 128: launch_r2cr<16, 8>(ra, grid, st); break;
-    case 256: launch_r2cr<16, 16>(ra, grid, st); break;
-    case 512: launch_r2cr<32, 16>(ra, grid, st); break;
-    case 1024: launch_r2cr<32, 32>(ra, grid, st); break;
+    case 64: launch_r2cr<8, 8>(ra, grid, st, inverse); break;
+    case 128: launch_r2cr<16, 8>(ra, grid, st, inverse); break;
+    case 256: launch_r2cr<16, 16>(ra, grid, st, inverse); break;
+    case 512: launch_r2cr<32, 16>(ra, grid, st, inverse); break;
+    case 1024: launch_r2cr<32, 32>(ra, grid, st, inverse); break;
     }
     return 0;
 }

@@ -159,4 +159,129 @@ r2crows_kernel(const R2CRArgs a) {
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* the transpose: half spectra (L + 1 complex per row) -> real rows of 2L    */
+/* ------------------------------------------------------------------------ */
+/*   t   one item per pair (k, L - k):  Z'[k] = E' + i O',  Z'[L-k] = conj(E' - i O'),
+ *       E' = Y[k] + conj Y[L-k],  O' = (Y[k] - conj Y[L-k]) w_n^-k   (c2r_pre_kernel; Im Y[0]
+ *       and Im Y[L] are ignored) -> two LDS planes [t][k]
+ *   A,B the unnormalised BACKWARD complex DFT of length L by the (re, im) swap identity:
+ *       stage A reads its inputs from the planes (swapped), stage B stores (Im, Re) as the
+ *       real pair (x[2j], x[2j+1])
+ */
+template <int R1, int R2>
+__global__ void __launch_bounds__(256, 2)
+c2rrows_kernel(const R2CRArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double plane[];
+    typedef R2CRGeom<R1, R2> G;
+    constexpr int L = G::L, T = G::T, QA = G::QA, QB = G::QB, SA = G::SA, ST = G::ST, SX = G::SX;
+    const int tid = threadIdx.x;
+
+    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
+    i64 tile = blk % a.ntiles;
+    i64 rest = blk / a.ntiles;
+    i64 soff = 0, doff = 0;
+    for (int d = 1; d < a.ndims; ++d) {
+        i64 idx = rest % a.dn[d];
+        rest /= a.dn[d];
+        soff += idx * a.dis[d];
+        doff += idx * a.dos[d];
+    }
+    const i64 t0 = tile * T;
+    const int Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
+    const double *src = a.src + soff + t0 * a.dis[0];
+    double *dst = a.dst + doff + t0 * a.dos[0];
+
+    /* ---- tangle into the planes (already swapped: zr holds Im Z', zi holds Re Z') */
+    double *zr = plane, *zi = plane + T * SX;
+    {
+        constexpr int NP = L / 2 + 1;
+        const int items = Tcur * NP;
+        for (int i = tid; i < items; i += 256) {
+            const int t = i / NP, k = i - t * NP;
+            const int km = L - k;
+            const double *row = src + (i64)t * a.dis[0];
+            cplx yk = *reinterpret_cast<const cplx *>(row + 2 * k);
+            cplx ym = *reinterpret_cast<const cplx *>(row + 2 * km);
+            if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+            const cplx e = c_make(yk.x + ym.x, yk.y - ym.y);
+            const cplx dd = c_make(yk.x - ym.x, yk.y + ym.y);
+            const cplx o = c_mul(dd, tw2(a.tw_lo, a.tw_hi, a.tw_shift, k));
+            /* Z'[k] = E' + i O' ; Z'[L-k] = conj(E' - i O') */
+            const double zkr = e.x - o.y, zki = e.y + o.x;
+            const double zmr = e.x + o.y, zmi = -(e.y - o.x);
+            zr[t * SX + k] = zki;  zi[t * SX + k] = zkr;
+            if (km != k && km != L) { zr[t * SX + km] = zmi;  zi[t * SX + km] = zmr; }
+        }
+    }
+    __syncthreads();
+
+    /* ---- stage A from the planes */
+    cplx x[QA][R1];
+    int at[QA], aa[QA];
+#pragma unroll
+    for (int u = 0; u < QA; ++u) {
+        int g = u * 256 + tid;
+        const int last = Tcur * R2 - 1;
+        g = g < last ? g : last;
+        at[u] = g / R2;
+        aa[u] = g - at[u] * R2;
+#pragma unroll
+        for (int i = 0; i < R1; ++i)
+            x[u][i] = c_make(zr[at[u] * SX + aa[u] + R2 * i], zi[at[u] * SX + aa[u] + R2 * i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < QA; ++u) {
+        RB<R1>::run(x[u]);
+        cplx pw[RB<R1>::bits];
+#pragma unroll
+        for (int s = 0; s < RB<R1>::bits; ++s) pw[s] = a.wL[(aa[u] << s) % L];
+        TwTreeR<R1, RB<R1>::bits - 1, 0, false, true>::run(x[u], pw, c_make(1.0, 0.0));
+    }
+
+    /* ---- exchange -> stage B owners (d fastest, then t) */
+    cplx y[QB][R2];
+    int bd[QB], bt[QB];
+#pragma unroll
+    for (int v = 0; v < QB; ++v) {
+        int j = v * 256 + tid;
+        const int last = Tcur * R1 - 1;
+        j = j < last ? j : last;
+        bt[v] = j / R1;
+        bd[v] = j - bt[v] * R1;
+    }
+#pragma unroll
+    for (int u = 0; u < QA; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[at[u] * ST + d * SA + aa[u]] = x[u][RB<R1>::slot(d)].x;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int q = 0; q < R2; ++q) y[v][q].x = plane[bt[v] * ST + bd[v] * SA + q];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < QA; ++u)
+#pragma unroll
+        for (int d = 0; d < R1; ++d) plane[at[u] * ST + d * SA + aa[u]] = x[u][RB<R1>::slot(d)].y;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < QB; ++v)
+#pragma unroll
+        for (int q = 0; q < R2; ++q) y[v][q].y = plane[bt[v] * ST + bd[v] * SA + q];
+
+    /* ---- stage B, store the pair (x[2j], x[2j+1]) = (Im, Re) of the swapped result */
+#pragma unroll
+    for (int v = 0; v < QB; ++v) {
+        RB<R2>::run(y[v]);
+        double *p = dst + (i64)bt[v] * a.dos[0] + 2 * bd[v];
+#pragma unroll
+        for (int c = 0; c < R2; ++c) {
+            const cplx w = y[v][RB<R2>::slot(c)];
+            *reinterpret_cast<cplx *>(p + (i64)c * (2 * R1)) = c_make(w.y, w.x);
+        }
+    }
+}
+
 #endif /* FA_R2CROWS_HPP */

@@ -125,7 +125,8 @@ enum {
     FFTW_AMD_K_P1024 = 1,       /* register-resident radix-32x32 kernel, tile of 8 */
     FFTW_AMD_K_RR = 2,          /* register-resident two-stage kernel, L = 64..512, tile of 8192/L */
     FFTW_AMD_K_R3 = 3,          /* register-resident three-stage kernels (rows up to 4096; strided up to 1008) */
-    FFTW_AMD_K_R2C = 4          /* fused real rows -> half spectra (r2crows.hpp), with FFTW_AMD_F_R2C_ROWS */
+    FFTW_AMD_K_R2C = 4,         /* fused real rows -> half spectra (r2crows.hpp), with FFTW_AMD_F_R2C_ROWS */
+    FFTW_AMD_K_C2R = 5          /* fused half spectra -> real rows, with FFTW_AMD_F_C2R_ROWS */
 };
 
 enum {
@@ -139,8 +140,10 @@ enum {
     FFTW_AMD_F_PERM_DST  = 1 << 7, /* copy: destination index through permutation */
     FFTW_AMD_F_CONJ_OUT  = 1 << 8, /* conjugate on store */
     FFTW_AMD_F_TW_IN     = 1 << 9, /* pass: the twiddle multiplies the INPUT element (l, q) instead of the output */
-    FFTW_AMD_F_R2C_ROWS  = 1 << 10 /* pass over real pairs (src_im = 1) that also does the r2c untangle for n = 2L:
+    FFTW_AMD_F_R2C_ROWS  = 1 << 10,/* pass over real pairs (src_im = 1) that also does the r2c untangle for n = 2L:
                                       stores L + 1 entries per row; tw_lo / tw_hi hold w_n^m (tw_n stays 0) */
+    FFTW_AMD_F_C2R_ROWS  = 1 << 11 /* the transpose: reads L + 1 spectrum entries per row, c2r tangle, backward
+                                      length-L pass, stores the real pairs (dst_im = 1) */
 };
 
 int fftw_amd_plan_num_steps(const fftw_plan p);

@@ -127,6 +127,18 @@ class Interp(object):
                 twb = twb + gi * dtw[i]
             rad = [s.radices[i] for i in range(s.nradices)]
             assert int(np.prod(rad)) == L if rad else L == 1
+            if s.flags & fa.F_C2R_ROWS:
+                # fused c2r: L + 1 spectrum entries per row -> 2L reals stored as L (re, im) pairs
+                g2 = _grids([L + 1] + dn)
+                so2 = sbase + g2[0] * s.is_l
+                for i, gi in enumerate(g2[1:]):
+                    so2 = so2 + gi * dis[i]
+                Y = _load(src, so2, s.src_im, 0)
+                Y[0] = Y[0].real
+                Y[L] = Y[L].real
+                xr = np.fft.irfft(Y, n=2 * L, axis=0) * (2 * L)
+                _store(dst, doff, s.dst_im, 0, xr[0::2] + 1j * xr[1::2])
+                return
             x = _load(src, soff, s.src_im, s.flags)
             if s.tw_n and (s.flags & fa.F_TW_IN):
                 m = l * twb

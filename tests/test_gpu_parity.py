@@ -607,3 +607,22 @@ def test_fused_real_rows_kernel(torch_dev, n):
         p.execute()
         torch.cuda.synchronize()
         assert aerror(yd.cpu().numpy(), oracle_r2c(x, shape, 2).reshape(2, hs)) < TOL, shape
+        # and back through the fused c2r rows kernel
+        from util import oracle_c2r
+        y = yd.cpu().numpy().reshape(-1).copy()
+        zd = torch.zeros((2, size), dtype=torch.float64, device=dev)
+        q = fa.plan_many_dft_c2r(len(shape), list(shape), 2, yd, None, 1, hs, zd, None, 1, size)
+        assert "c2r-rows" in q.sprint(), q.sprint()
+        q.execute()
+        torch.cuda.synchronize()
+        assert aerror(zd.cpu().numpy().reshape(-1), oracle_c2r(y, shape, 2)) < TOL, shape
+    # batched 1-D c2r with a ragged last tile; the input is preserved
+    y = oracle_r2c(rrand(rng, hm, n), (n,), hm)
+    yd = torch.from_numpy(y).to(dev)
+    zd = torch.zeros((hm, n), dtype=torch.float64, device=dev)
+    q = fa.plan_many_dft_c2r(1, [n], hm, yd, None, 1, n // 2 + 1, zd, None, 1, n)
+    assert "c2r-rows" in q.sprint() and "tangle" not in q.sprint(), q.sprint()
+    q.execute()
+    torch.cuda.synchronize()
+    assert aerror(zd.cpu().numpy().reshape(-1), oracle_c2r(y, (n,), hm)) < TOL
+    assert np.array_equal(yd.cpu().numpy(), y)
