@@ -209,7 +209,9 @@ int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *co
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
     const int T = fa_hip_r2c_rows_tile(d->L);
-    if (T <= 0 || d->tile != T || d->src_im != 1 || d->dst_im != 1 || d->is_l != 2 || d->os_l != 2) {
+    const int epi = (d->flags & FFTW_AMD_F_R2C_ROWS) ? (int)d->aux_valid : 0;
+    if (T <= 0 || d->tile != T || d->src_im != 1 || d->is_l != 2 ||
+        (epi == 0 && (d->dst_im != 1 || d->os_l != 2))) {
         fprintf(stderr, "fftw3_amd: internal error: fused r2c rows step with an unsupported layout\n");
         abort();
     }
@@ -225,7 +227,13 @@ int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *co
     }
     ra.src = bufs[d->src_buf] + sbase;
     ra.dst = bufs[d->dst_buf] + dbase;
-    if (((uintptr_t)ra.src % 16) || ((uintptr_t)ra.dst % 16)) {
+    ra.os_k = d->os_l;
+    ra.dst_im = d->dst_im;
+    ra.flags = 0;
+    ra.r2r = epi;
+    ra.twmul = (epi && d->aux_base > 0) ? (int)d->aux_base : 1;
+    ra.rn = epi == FFTW_AMD_R2R_POST_E00 ? d->aux_n / 2 + 1 : (epi == FFTW_AMD_R2R_POST_O00 ? d->aux_n / 2 - 1 : d->aux_n);
+    if (((uintptr_t)ra.src % 16) || (epi == 0 && ((uintptr_t)ra.dst % 16))) {
         fprintf(stderr, "fftw3_amd: fftw_execute_dft_r2c needs arrays aligned like the ones the plan was "
                         "created with (16 bytes)\n");
         abort();

@@ -958,18 +958,18 @@ static int axis_pass_count(i64 n) {
 /* the fused rows kernel loads 16-byte pairs and stores 16-byte complex numbers: every
    loop stride must keep that alignment, the user arrays must be 16-byte aligned, there must
    be a loop to tile over, and the tile dim must not be a two-level (pair) dim */
-static int r2c_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc in, fa_loc out) {
+static int r2c_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc in, fa_loc out, int epi) {
     int j, rows = 0;
     if (getenv("FFTW_AMD_NO_R2CROWS")) return 0;
     for (j = 0; j < ax->nloops; ++j) {
-        if ((ax->loops[j].is % 2) || (ax->loops[j].os % 2)) return 0;
+        if ((ax->loops[j].is % 2) || (!epi && (ax->loops[j].os % 2))) return 0;
         /* emit_pass would fold such a loop into a two-level tile dim, which this kernel lacks */
         if (ax->loops[j].n == 2 && (iabs(ax->loops[j].is) == 2 || iabs(ax->loops[j].os) == 2)) return 0;
         if (ax->loops[j].n > 1) rows = 1;
     }
     if (!rows) return 0;
     if (in.buf == 0 && (((size_t)p->ri % 16) || (in.base % 2))) return 0;
-    if (out.buf == 1 && (((size_t)p->ro % 16) || (out.base % 2))) return 0;
+    if (!epi && out.buf == 1 && (((size_t)p->ro % 16) || (out.base % 2))) return 0;
     if (in.buf == 1 && (((size_t)p->ro % 16) || (in.base % 2))) return 0;
     return 1;
 }
@@ -1071,8 +1071,8 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
         step_set_dims(p, s, d, nd, -1);
         p->est_flops += 20.0 * (double)m;
         buf_release(p, zbuf);
-    } else if (nl % 2 == 0 && nl >= 2 && epi == 0 && ps == 2 && pim == 1 && cs == 2 && out.im == 1 &&
-               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && r2c_rows_layout_ok(p, &ax, in, out)) {
+    } else if (nl % 2 == 0 && nl >= 2 && ps == 2 && pim == 1 && (epi != 0 || (cs == 2 && out.im == 1)) &&
+               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && r2c_rows_layout_ok(p, &ax, in, out, epi)) {
         /* contiguous real rows of a supported length: the half-length complex DFT and the
            untangle in ONE trip (r2crows.hpp) instead of a pass plus an untangle step */
         sdim d[FA_MAXLOOPS];
@@ -1084,14 +1084,25 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
             d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = ax.loops[j].os;
             d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
         }
-        emit_pass(p, src, out, nl / 2, 2, 2, d, nd, 0, FFTW_AMD_F_R2C_ROWS);
+        emit_pass(p, src, out, nl / 2, 2, epi ? cs : 2, d, nd, 0, FFTW_AMD_F_R2C_ROWS);
         s = &p->steps[p->nsteps - 1];
         s->variant = FFTW_AMD_K_R2C;
         s->tile = fa_hip_r2c_rows_tile((int)(nl / 2));
         s->tile_lo_n = 1;
-        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        /* aux_n = n, aux_valid = fused r2r epilogue (0: plain half spectrum), aux_base = index
+           multiplier of the untangle twiddle in the table (4 with the modulus-4n table of the
+           DCT-II / DST-II epilogues, see r2r_fuse_tables) */
+        s->aux_n = nl;
+        s->aux_valid = epi;
+        if (epi == FFTW_AMD_R2R_POST_E10 || epi == FFTW_AMD_R2R_POST_O10) {
+            tab_tw2(p, 4 * nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+            s->aux_base = 4;
+        } else {
+            tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+            s->aux_base = 1;
+        }
         p->est_flops += 8.0 * (double)(nl / 2);
-        return 0;
+        return epi != 0;
     } else if (nl % 2 == 0 && nl >= 2) {
         /* z[j] = x[2j] + i x[2j+1]; Z = DFT_{n/2}(z); untangle */
         i64 h = nl / 2, zts, lts[FA_MAXLOOPS], total;
@@ -2032,7 +2043,7 @@ char *fa_sprint(const plan *p) {
             /* which kernel runs the pass: reg32x32 / reg2 / reg3 = register-resident
                (pass1024 / passrr / pass3s), lds = runtime-radix LDS kernel + its radices */
             len += (size_t)snprintf(s + len, cap - len, "-%d/", d->L);
-            if (d->variant == FFTW_AMD_K_R2C) len += (size_t)snprintf(s + len, cap - len, "r2c-rows");
+            if (d->variant == FFTW_AMD_K_R2C) len += (size_t)snprintf(s + len, cap - len, d->aux_valid ? "r2c-rows+r2r-post" : "r2c-rows");
             else if (d->variant == FFTW_AMD_K_C2R) len += (size_t)snprintf(s + len, cap - len, "c2r-rows");
             else if (d->variant == FFTW_AMD_K_P1024) len += (size_t)snprintf(s + len, cap - len, "reg32x32");
             else if (d->variant == FFTW_AMD_K_RR) len += (size_t)snprintf(s + len, cap - len, "reg2");

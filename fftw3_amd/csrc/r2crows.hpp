@@ -33,9 +33,15 @@ template <int R1, int R2> struct R2CRGeom {
     static constexpr int lds_doubles = (EX > 2 * T * SX ? EX : 2 * T * SX) + 16;
 };
 
+#include "r2r_epi.hpp"
+
 struct R2CRArgs {
     const double *src;      /* real rows: row t at src + t * dis[0] (+ loops), unit stride */
-    double *dst;            /* complex rows of L + 1 entries, unit stride (2 doubles) */
+    double *dst;            /* complex rows of L + 1 entries, unit stride (2 doubles); or, with an r2r
+                               epilogue, real rows of stride os_k */
+    i64 os_k, dst_im;       /* epilogue addressing (epi_store) */
+    i64 rn;                 /* r2r length */
+    int r2r, twmul, flags;  /* FFTW_AMD_R2R_POST_* or 0; untangle twiddle = table entry k * twmul */
     i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
     const cplx *wL;         /* w_L^m */
     const cplx *tw_lo;      /* two-level table of w_n^m, n = 2L */
@@ -149,13 +155,20 @@ r2crows_kernel(const R2CRArgs a) {
         const double er = 0.5 * (ar + br), ei = 0.5 * (ai - bi);
         const double dr = 0.5 * (ar - br), di = 0.5 * (ai + bi);
         const cplx o = c_make(di, -dr);                         /* -i D */
-        const cplx p = c_mulc(o, tw2(a.tw_lo, a.tw_hi, a.tw_shift, k));
+        const cplx p = c_mulc(o, tw2(a.tw_lo, a.tw_hi, a.tw_shift, (i64)k * a.twmul));
         cplx yk = c_make(er + p.x, ei + p.y);
         cplx ym = c_make(er - p.x, -(ei - p.y));
         if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
-        double *row = dst + (i64)t * a.dos[0];
-        *reinterpret_cast<cplx *>(row + 2 * k) = yk;
-        if (km != k) *reinterpret_cast<cplx *>(row + 2 * km) = ym;
+        if (a.r2r == 0) {
+            double *row = dst + (i64)t * a.dos[0];
+            *reinterpret_cast<cplx *>(row + 2 * k) = yk;
+            if (km != k) *reinterpret_cast<cplx *>(row + 2 * km) = ym;
+        } else {
+            /* r2r epilogue (R2HC, DHT, DCT-II, DST-II, DCT-I, DST-I): reals of stride os_k */
+            const i64 doff = (dst - a.dst) + (i64)t * a.dos[0];
+            epi_store(a, doff, k, yk);
+            if (km != k) epi_store(a, doff, km, ym);
+        }
     }
 }
 

@@ -159,8 +159,18 @@ class Interp(object):
                 Y[0] = Y[0].real
                 nyq = (y[0].real - y[0].imag) + 0j                   # Y[L] = Re Z[0] - Im Z[0]
                 dbase_off = doff - l * s.os_l                        # offset of entry 0 of every row
-                _store(dst, dbase_off + l * s.os_l, s.dst_im, s.flags, Y)
-                _store(dst, (dbase_off + L * s.os_l)[0:1], s.dst_im, s.flags, nyq[None])
+                if s.aux_valid:
+                    # fused r2r epilogue on the L + 1 half-spectrum entries (aux_base = twiddle multiplier)
+                    import types
+                    sh = types.SimpleNamespace(variant=int(s.aux_valid), os_l=s.os_l, dst_im=s.dst_im, flags=0,
+                                               aux_n=s.aux_n, tw_lo=s.tw_lo, tw_hi=s.tw_hi, tw_shift=s.tw_shift)
+                    Y = E + O * np.conj(self.tw2(s, k * max(1, int(s.aux_base))))
+                    Y[0] = Y[0].real
+                    self._epi_store(sh, dst, dbase_off[0:1], np.int64(L), nyq[None])
+                    self._epi_store(sh, dst, dbase_off, k, Y)
+                else:
+                    _store(dst, dbase_off + l * s.os_l, s.dst_im, s.flags, Y)
+                    _store(dst, (dbase_off + L * s.os_l)[0:1], s.dst_im, s.flags, nyq[None])
             else:
                 _store(dst, doff, s.dst_im, s.flags, y)
         elif s.kind in (fa.STEP_COPY, fa.STEP_HERM_EXPAND):

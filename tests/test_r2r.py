@@ -527,3 +527,31 @@ def test_gpu_r2r_measure_mode_and_wisdom():
     q.sync()
     assert aerror(dy.cpu().numpy(), oracle_r2r(x, [n], [fa.RODFT10], howmany=hm)) <= TOL
     fa.forget_wisdom()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", [(fa.R2HC, 1024), (fa.DHT, 512), (fa.REDFT10, 2048), (fa.RODFT10, 256),
+                                    (fa.REDFT00, 513), (fa.RODFT00, 511), (fa.REDFT10, 128)])
+def test_gpu_r2r_fused_rows_epilogues(kind, n):
+    """short contiguous r2r rows: the inner real transform and the r2r post-processing run in the
+    fused rows kernel (one trip, or shuffle + one trip); ragged batch, also as the last axis of 2-D"""
+    import torch
+    rng = np.random.default_rng(n + kind)
+    hm = 37
+    x = rrand(rng, hm * n)
+    dx = _dev(x)
+    dy = torch.zeros_like(dx)
+    p = fa.plan_many_r2r(1, [n], hm, dx, None, 1, n, dy, None, 1, n, [kind])
+    assert "r2c-rows+r2r-post" in p.sprint(), p.sprint()
+    p.execute()
+    p.sync()
+    assert aerror(dy.cpu().numpy(), oracle_r2r(x, [n], [kind], howmany=hm)) <= TOL
+    shape, kinds = [24, n], [fa.REDFT01, kind]
+    x = rrand(rng, 2 * 24 * n)
+    dx = _dev(x)
+    dy = torch.zeros_like(dx)
+    p = fa.plan_many_r2r(2, shape, 2, dx, None, 1, 24 * n, dy, None, 1, 24 * n, kinds)
+    assert "r2c-rows+r2r-post" in p.sprint(), p.sprint()
+    p.execute()
+    p.sync()
+    assert aerror(dy.cpu().numpy(), oracle_r2r(x, shape, kinds, howmany=2)) <= TOL
