@@ -209,9 +209,11 @@ int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *co
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
     const int T = fa_hip_r2c_rows_tile(d->L);
-    const int epi = (d->flags & FFTW_AMD_F_R2C_ROWS) ? (int)d->aux_valid : 0;
-    if (T <= 0 || d->tile != T || d->src_im != 1 || d->is_l != 2 ||
-        (epi == 0 && (d->dst_im != 1 || d->os_l != 2))) {
+    const bool fwd = (d->flags & FFTW_AMD_F_R2C_ROWS) != 0;
+    const int epi = (int)d->aux_valid;                 /* fused r2r epilogue (r2c) / prologue (c2r), or 0 */
+    const bool real_src = !fwd && epi, real_dst = fwd && epi;
+    if (T <= 0 || d->tile != T || (!real_src && (d->src_im != 1 || d->is_l != 2)) ||
+        (!real_dst && (d->dst_im != 1 || d->os_l != 2))) {
         fprintf(stderr, "fftw3_amd: internal error: fused r2c rows step with an unsupported layout\n");
         abort();
     }
@@ -229,11 +231,13 @@ int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *co
     ra.dst = bufs[d->dst_buf] + dbase;
     ra.os_k = d->os_l;
     ra.dst_im = d->dst_im;
+    ra.is_k = d->is_l;
+    ra.src_im = d->src_im;
     ra.flags = 0;
     ra.r2r = epi;
     ra.twmul = (epi && d->aux_base > 0) ? (int)d->aux_base : 1;
     ra.rn = epi == FFTW_AMD_R2R_POST_E00 ? d->aux_n / 2 + 1 : (epi == FFTW_AMD_R2R_POST_O00 ? d->aux_n / 2 - 1 : d->aux_n);
-    if (((uintptr_t)ra.src % 16) || (epi == 0 && ((uintptr_t)ra.dst % 16))) {
+    if ((!real_src && ((uintptr_t)ra.src % 16)) || (!real_dst && ((uintptr_t)ra.dst % 16))) {
         fprintf(stderr, "fftw3_amd: fftw_execute_dft_r2c needs arrays aligned like the ones the plan was "
                         "created with (16 bytes)\n");
         abort();

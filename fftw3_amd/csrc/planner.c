@@ -974,17 +974,17 @@ static int r2c_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc in, fa_lo
     return 1;
 }
 
-static int c2r_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc cur, fa_loc out) {
+static int c2r_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc cur, fa_loc out, int pro) {
     int j, rows = 0;
     if (getenv("FFTW_AMD_NO_R2CROWS")) return 0;
     for (j = 0; j < ax->nloops; ++j) {
-        if ((ax->loops[j].is % 2) || (ax->loops[j].os % 2)) return 0;
+        if ((!pro && (ax->loops[j].is % 2)) || (ax->loops[j].os % 2)) return 0;
         if (ax->loops[j].n == 2 && (iabs(ax->loops[j].is) == 2 || iabs(ax->loops[j].os) == 2)) return 0;
         if (ax->loops[j].n > 1) rows = 1;
     }
     if (!rows) return 0;
-    if (cur.buf == 0 && (((size_t)p->ri % 16) || (cur.base % 2))) return 0;
-    if (cur.buf == 1 && (((size_t)p->ro % 16) || (cur.base % 2))) return 0;
+    if (!pro && cur.buf == 0 && (((size_t)p->ri % 16) || (cur.base % 2))) return 0;
+    if (!pro && cur.buf == 1 && (((size_t)p->ro % 16) || (cur.base % 2))) return 0;
     if (out.buf == 1 && (((size_t)p->ro % 16) || (out.base % 2))) return 0;
     return 1;
 }
@@ -1263,8 +1263,8 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         for (j = 0; j < q_ax.nloops; ++j) q_ax.loops[j].is = lts[j];
         fa_emit_axis(p, &q_ax);
         buf_release(p, zbuf);
-    } else if (nl % 2 == 0 && nl >= 2 && pro == 0 && ps == 2 && pim == 1 && cs == 2 && cur.im == 1 &&
-               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && c2r_rows_layout_ok(p, &ax, cur, out)) {
+    } else if (nl % 2 == 0 && nl >= 2 && ps == 2 && pim == 1 && (pro != 0 || (cs == 2 && cur.im == 1)) &&
+               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && c2r_rows_layout_ok(p, &ax, cur, out, pro)) {
         /* contiguous rows of a supported length: tangle + backward half-length DFT in ONE trip */
         sdim d[FA_MAXLOOPS];
         int nd = 0;
@@ -1275,12 +1275,20 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
             d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = ax.loops[j].os;
             d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
         }
-        emit_pass(p, cur, dstp, nl / 2, 2, 2, d, nd, 0, FFTW_AMD_F_C2R_ROWS);
+        emit_pass(p, cur, dstp, nl / 2, pro ? cs : 2, 2, d, nd, 0, FFTW_AMD_F_C2R_ROWS);
         s = &p->steps[p->nsteps - 1];
         s->variant = FFTW_AMD_K_C2R;
         s->tile = fa_hip_r2c_rows_tile((int)(nl / 2));
         s->tile_lo_n = 1;
-        tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+        s->aux_n = nl;              /* as in the r2c rows step: n, fused r2r prologue, twiddle multiplier */
+        s->aux_valid = pro;
+        if (pro == FFTW_AMD_R2R_PRE_E01 || pro == FFTW_AMD_R2R_PRE_O01) {
+            tab_tw2(p, 4 * nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+            s->aux_base = 4;
+        } else {
+            tab_tw2(p, nl, &s->tw_lo, &s->tw_hi, &s->tw_shift);
+            s->aux_base = 1;
+        }
         p->est_flops += 8.0 * (double)(nl / 2);
     } else if (nl % 2 == 0 && nl >= 2) {
         i64 h = nl / 2, zts, lts[FA_MAXLOOPS], total;
@@ -2044,7 +2052,7 @@ char *fa_sprint(const plan *p) {
                (pass1024 / passrr / pass3s), lds = runtime-radix LDS kernel + its radices */
             len += (size_t)snprintf(s + len, cap - len, "-%d/", d->L);
             if (d->variant == FFTW_AMD_K_R2C) len += (size_t)snprintf(s + len, cap - len, d->aux_valid ? "r2c-rows+r2r-post" : "r2c-rows");
-            else if (d->variant == FFTW_AMD_K_C2R) len += (size_t)snprintf(s + len, cap - len, "c2r-rows");
+            else if (d->variant == FFTW_AMD_K_C2R) len += (size_t)snprintf(s + len, cap - len, d->aux_valid ? "c2r-rows+r2r-pre" : "c2r-rows");
             else if (d->variant == FFTW_AMD_K_P1024) len += (size_t)snprintf(s + len, cap - len, "reg32x32");
             else if (d->variant == FFTW_AMD_K_RR) len += (size_t)snprintf(s + len, cap - len, "reg2");
             else if (d->variant == FFTW_AMD_K_R3) len += (size_t)snprintf(s + len, cap - len, "reg3");

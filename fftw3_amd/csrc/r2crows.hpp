@@ -40,6 +40,7 @@ struct R2CRArgs {
     double *dst;            /* complex rows of L + 1 entries, unit stride (2 doubles); or, with an r2r
                                epilogue, real rows of stride os_k */
     i64 os_k, dst_im;       /* epilogue addressing (epi_store) */
+    i64 is_k, src_im;       /* prologue addressing (pro_load, c2r side) */
     i64 rn;                 /* r2r length */
     int r2r, twmul, flags;  /* FFTW_AMD_R2R_POST_* or 0; untangle twiddle = table entry k * twmul */
     i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
@@ -213,13 +214,21 @@ c2rrows_kernel(const R2CRArgs a) {
         for (int i = tid; i < items; i += 256) {
             const int t = i / NP, k = i - t * NP;
             const int km = L - k;
-            const double *row = src + (i64)t * a.dis[0];
-            cplx yk = *reinterpret_cast<const cplx *>(row + 2 * k);
-            cplx ym = *reinterpret_cast<const cplx *>(row + 2 * km);
+            cplx yk, ym;
+            if (a.r2r == 0) {
+                const double *row = src + (i64)t * a.dis[0];
+                yk = *reinterpret_cast<const cplx *>(row + 2 * k);
+                ym = *reinterpret_cast<const cplx *>(row + 2 * km);
+            } else {
+                /* r2r prologue (HC2R, DCT-III, DST-III): spectrum entries built from the real input */
+                const i64 so = (src - a.src) + (i64)t * a.dis[0];
+                yk = pro_load(a, so, k);
+                ym = pro_load(a, so, km);
+            }
             if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
             const cplx e = c_make(yk.x + ym.x, yk.y - ym.y);
             const cplx dd = c_make(yk.x - ym.x, yk.y + ym.y);
-            const cplx o = c_mul(dd, tw2(a.tw_lo, a.tw_hi, a.tw_shift, k));
+            const cplx o = c_mul(dd, tw2(a.tw_lo, a.tw_hi, a.tw_shift, (i64)k * a.twmul));
             /* Z'[k] = E' + i O' ; Z'[L-k] = conj(E' - i O') */
             const double zkr = e.x - o.y, zki = e.y + o.x;
             const double zmr = e.x + o.y, zmi = -(e.y - o.x);

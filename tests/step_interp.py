@@ -133,7 +133,15 @@ class Interp(object):
                 so2 = sbase + g2[0] * s.is_l
                 for i, gi in enumerate(g2[1:]):
                     so2 = so2 + gi * dis[i]
-                Y = _load(src, so2, s.src_im, 0)
+                if s.aux_valid:
+                    # fused r2r prologue: the spectrum entries are built from the real input
+                    import types
+                    sh = types.SimpleNamespace(variant=int(s.aux_valid), is_l=s.is_l, src_im=s.src_im, aux_n=s.aux_n,
+                                               tw_lo=s.tw_lo, tw_hi=s.tw_hi, tw_shift=s.tw_shift)
+                    Y = self._pro_load(sh, src, so2 - g2[0] * s.is_l, g2[0])
+                    Y = np.array(np.broadcast_to(Y, np.broadcast(so2, g2[0]).shape), dtype=np.complex128)
+                else:
+                    Y = _load(src, so2, s.src_im, 0)
                 Y[0] = Y[0].real
                 Y[L] = Y[L].real
                 xr = np.fft.irfft(Y, n=2 * L, axis=0) * (2 * L)

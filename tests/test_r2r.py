@@ -555,3 +555,29 @@ def test_gpu_r2r_fused_rows_epilogues(kind, n):
     p.execute()
     p.sync()
     assert aerror(dy.cpu().numpy(), oracle_r2r(x, shape, kinds, howmany=2)) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", [(fa.HC2R, 1024), (fa.REDFT01, 2048), (fa.RODFT01, 256), (fa.HC2R, 128)])
+def test_gpu_r2r_fused_rows_prologues(kind, n):
+    """the transposed kinds: the r2r pre-processing runs inside the fused c2r rows kernel"""
+    import torch
+    rng = np.random.default_rng(n + kind)
+    hm = 37
+    x = rrand(rng, hm * n)
+    dx = _dev(x)
+    dy = torch.zeros_like(dx)
+    p = fa.plan_many_r2r(1, [n], hm, dx, None, 1, n, dy, None, 1, n, [kind])
+    assert "c2r-rows+r2r-pre" in p.sprint(), p.sprint()
+    p.execute()
+    p.sync()
+    assert aerror(dy.cpu().numpy(), oracle_r2r(x, [n], [kind], howmany=hm)) <= TOL
+    assert np.array_equal(dx.cpu().numpy(), x)
+    shape, kinds = [20, n], [fa.RODFT10, kind]
+    x = rrand(rng, 2 * 20 * n)
+    dx = _dev(x)
+    p = fa.plan_many_r2r(2, shape, 2, dx, None, 1, 20 * n, dx, None, 1, 20 * n, kinds)     # in place
+    assert "c2r-rows+r2r-pre" in p.sprint(), p.sprint()
+    p.execute()
+    p.sync()
+    assert aerror(dx.cpu().numpy(), oracle_r2r(x, shape, kinds, howmany=2)) <= TOL
