@@ -958,19 +958,19 @@ static int axis_pass_count(i64 n) {
 /* the fused rows kernel loads 16-byte pairs and stores 16-byte complex numbers: every
    loop stride must keep that alignment, the user arrays must be 16-byte aligned, there must
    be a loop to tile over, and the tile dim must not be a two-level (pair) dim */
-static int r2c_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc in, fa_loc out, int epi) {
+static int r2c_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc in, fa_loc out, int epi, int pre) {
     int j, rows = 0;
     if (getenv("FFTW_AMD_NO_R2CROWS")) return 0;
     for (j = 0; j < ax->nloops; ++j) {
-        if ((ax->loops[j].is % 2) || (!epi && (ax->loops[j].os % 2))) return 0;
+        if ((!pre && (ax->loops[j].is % 2)) || (!epi && (ax->loops[j].os % 2))) return 0;
         /* emit_pass would fold such a loop into a two-level tile dim, which this kernel lacks */
         if (ax->loops[j].n == 2 && (iabs(ax->loops[j].is) == 2 || iabs(ax->loops[j].os) == 2)) return 0;
         if (ax->loops[j].n > 1) rows = 1;
     }
     if (!rows) return 0;
-    if (in.buf == 0 && (((size_t)p->ri % 16) || (in.base % 2))) return 0;
+    if (!pre && in.buf == 0 && (((size_t)p->ri % 16) || (in.base % 2))) return 0;
     if (!epi && out.buf == 1 && (((size_t)p->ro % 16) || (out.base % 2))) return 0;
-    if (in.buf == 1 && (((size_t)p->ro % 16) || (in.base % 2))) return 0;
+    if (!pre && in.buf == 1 && (((size_t)p->ro % 16) || (in.base % 2))) return 0;
     return 1;
 }
 
@@ -1017,7 +1017,7 @@ static void r2r_fuse_tables(plan *p, fftw_amd_step_desc *s, i64 nl, int mode) {
    r2r emitters use ps = any, pim = 1: pairs stay adjacent even when other loops are
    innermost, so the register kernels take the first pass. */
 static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs, fa_loc out, i64 cs, int epi,
-                         i64 ps, i64 pim) {
+                         i64 ps, i64 pim, int pre) {
     fa_axis ax = *axp;
     i64 half = nl / 2 + 1;
     int j;
@@ -1071,8 +1071,9 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
         step_set_dims(p, s, d, nd, -1);
         p->est_flops += 20.0 * (double)m;
         buf_release(p, zbuf);
-    } else if (nl % 2 == 0 && nl >= 2 && ps == 2 && pim == 1 && (epi != 0 || (cs == 2 && out.im == 1)) &&
-               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && r2c_rows_layout_ok(p, &ax, in, out, epi)) {
+    } else if (nl % 2 == 0 && nl >= 2 && (pre != 0 || (ps == 2 && pim == 1)) &&
+               (epi != 0 || (cs == 2 && out.im == 1)) &&
+               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && r2c_rows_layout_ok(p, &ax, in, out, epi, pre)) {
         /* contiguous real rows of a supported length: the half-length complex DFT and the
            untangle in ONE trip (r2crows.hpp) instead of a pass plus an untangle step */
         sdim d[FA_MAXLOOPS];
@@ -1084,9 +1085,10 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
             d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = ax.loops[j].os;
             d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
         }
-        emit_pass(p, src, out, nl / 2, 2, epi ? cs : 2, d, nd, 0, FFTW_AMD_F_R2C_ROWS);
+        emit_pass(p, src, out, nl / 2, pre ? rs : 2, epi ? cs : 2, d, nd, 0, FFTW_AMD_F_R2C_ROWS);
         s = &p->steps[p->nsteps - 1];
         s->variant = FFTW_AMD_K_R2C;
+        s->aux_buf = pre ? pre : -1;     /* r2r pre-processing gathered inside the row (FFTW_AMD_R2R_PRE_*) */
         s->tile = fa_hip_r2c_rows_tile((int)(nl / 2));
         s->tile_lo_n = 1;
         /* aux_n = n, aux_valid = fused r2r epilogue (0: plain half spectrum), aux_base = index
@@ -1186,7 +1188,7 @@ static void build_r2c(plan *p) {
     memset(&ax, 0, sizeof(ax));
     if (collect_loops(p, p->dims, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
 
-    emit_r2c_axis(p, nl, &ax, in, p->dims[r - 1].is, out, p->dims[r - 1].os, 0, 0, 0);
+    emit_r2c_axis(p, nl, &ax, in, p->dims[r - 1].is, out, p->dims[r - 1].os, 0, 0, 0, 0);
 
     for (a = r - 2; a >= 0; --a) {
         fa_axis cx;
@@ -1479,7 +1481,7 @@ static fftw_amd_step_desc *emit_r2r_step(plan *p, int mode, i64 n, i64 K, i64 tw
 static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc in, i64 rs,
                           fa_loc out, i64 os) {
     enum { IN_R2C, IN_C2R, IN_C2C };
-    int pre = 0, post = 0, inner = IN_R2C, j, nl = axp->nloops, fuse_pre = 0, fuse_post = 0;
+    int pre = 0, post = 0, inner = IN_R2C, j, nl = axp->nloops, fuse_pre = 0, fuse_post = 0, rows_pre = 0;
     i64 N = n, cntA = 0, unitA = 1, cntB = 0, unitB = 1, twmod = 0, Kpre = 0, Kpost = 0;
     i64 lis_user[FA_MAXLOOPS], los_user[FA_MAXLOOPS], ltsA[FA_MAXLOOPS], ltsB[FA_MAXLOOPS];
     i64 tsA = 0, tsB = 0, psA = 0, pimA = 0, psB = 0, pimB = 0;
@@ -1543,6 +1545,12 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
     /* even inner length: the untangle / tangle step of the real transform does the
        r2r post / pre processing itself, one pass over the data less */
     if (inner == IN_R2C && post && r2r_can_fuse(N)) { fuse_post = 1; cntB = 0; }
+    /* short rows: the fused real-rows kernel also gathers the pre-processed sequence from the
+       user's row itself -- the whole r2r axis is one trip */
+    if (fuse_post && pre && pre != FFTW_AMD_R2R_PRE_HC2R && fa_hip_r2c_rows_tile((int)(N / 2)) > 0) {
+        fa_axis tax = *axp;
+        if (r2c_rows_layout_ok(p, &tax, in, out, post, pre)) { rows_pre = pre; cntA = 0; }
+    }
     if (inner == IN_C2R && pre && r2r_can_fuse(N)) { fuse_pre = 1; cntA = 0; }
 
     /* Real scratch sequences of even length are laid out as adjacent pairs
@@ -1581,7 +1589,7 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
     psA = (unitA == 1) ? (pairA ? tsA : 2 * tsA) : 0;  pimA = (unitA == 1) ? (pairA ? 1 : tsA) : 0;
     psB = (unitB == 1) ? (pairB ? tsB : 2 * tsB) : 0;  pimB = (unitB == 1) ? (pairB ? 1 : tsB) : 0;
 
-    if (pre && !fuse_pre) {
+    if (pre && !fuse_pre && !rows_pre) {
         fa_loc dA = A;
         if (unitA == 1) dA.im = pimA;          /* real sequence: element j at (j >> 1) psA + (j & 1) pimA */
         emit_r2r_step(p, pre, n, Kpre, twmod, in, rs, dA, unitA == 1 ? psA : tsA, axp, lis_user, ltsA, 0);
@@ -1593,15 +1601,18 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
     if (inner == IN_R2C) {
         fa_loc s = pre ? A : in;
         for (j = 0; j < nl; ++j) {
-            iax.loops[j].is = pre ? ltsA[j] : lis_user[j];
+            iax.loops[j].is = (pre && !rows_pre) ? ltsA[j] : lis_user[j];
             iax.loops[j].os = fuse_post ? los_user[j] : ltsB[j];
         }
         s.im = 0;
-        if (fuse_post) {
-            emit_r2c_axis(p, N, &iax, s, pre ? pimA : rs, out, os, post, pre ? psA : 0, pre ? pimA : 0);
+        if (rows_pre) {
+            emit_r2c_axis(p, N, &iax, in, rs, out, os, post, 0, 0, rows_pre);
+            post = 0;
+        } else if (fuse_post) {
+            emit_r2c_axis(p, N, &iax, s, pre ? pimA : rs, out, os, post, pre ? psA : 0, pre ? pimA : 0, 0);
             post = 0;
         } else {
-            emit_r2c_axis(p, N, &iax, s, pre ? pimA : rs, B, tsB, 0, pre ? psA : 0, pre ? pimA : 0);
+            emit_r2c_axis(p, N, &iax, s, pre ? pimA : rs, B, tsB, 0, pre ? psA : 0, pre ? pimA : 0, 0);
         }
     } else if (inner == IN_C2R) {
         fa_loc d = post ? B : out;

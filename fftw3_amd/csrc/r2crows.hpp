@@ -43,6 +43,8 @@ struct R2CRArgs {
     i64 is_k, src_im;       /* prologue addressing (pro_load, c2r side) */
     i64 rn;                 /* r2r length */
     int r2r, twmul, flags;  /* FFTW_AMD_R2R_POST_* or 0; untangle twiddle = table entry k * twmul */
+    int pre;                /* r2c rows: FFTW_AMD_R2R_PRE_E10 / O10 / E00 / O00 = gather the real sequence from the
+                               user's r2r input (element stride is_k) instead of loading pairs; 0 = plain */
     i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
     const cplx *wL;         /* w_L^m */
     const cplx *tw_lo;      /* two-level table of w_n^m, n = 2L */
@@ -51,6 +53,30 @@ struct R2CRArgs {
     int tw_shift;
     int ndims;
 };
+
+/* element m of the real sequence the inner r2c of an r2r transform works on, gathered from
+   the user's row (what the PRE_* modes of r2r_kernel write to scratch):
+   N = 2L is the inner length, a.rn the r2r length n */
+template <class A>
+FA_DEV double r2r_pre_elem(const A &a, const double *row, i64 m) {
+    const i64 n = a.rn;
+    switch (a.pre) {
+    case FFTW_AMD_R2R_PRE_E10:
+    case FFTW_AMD_R2R_PRE_O10: {
+        const i64 si = (m < (n + 1) / 2) ? 2 * m : 2 * n - 1 - 2 * m;
+        const double v = row[si * a.is_k];
+        return (a.pre == FFTW_AMD_R2R_PRE_O10 && (si & 1)) ? -v : v;
+    }
+    case FFTW_AMD_R2R_PRE_E00:
+        return row[(m < n ? m : 2 * (n - 1) - m) * a.is_k];
+    case FFTW_AMD_R2R_PRE_O00:
+        if (m >= 1 && m <= n) return row[(m - 1) * a.is_k];
+        if (m > n + 1) return -row[(2 * (n + 1) - m - 1) * a.is_k];
+        return 0.0;
+    default:
+        return 0.0;
+    }
+}
 
 template <int R1, int R2>
 __global__ void __launch_bounds__(256, 2)
@@ -85,9 +111,19 @@ r2crows_kernel(const R2CRArgs a) {
         g = g < last ? g : last;
         at[u] = g / R2;
         aa[u] = g - at[u] * R2;
-        const double *p = src + (i64)at[u] * a.dis[0] + 2 * aa[u];
+        if (a.pre == 0) {
+            const double *p = src + (i64)at[u] * a.dis[0] + 2 * aa[u];
 #pragma unroll
-        for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + (i64)i * (2 * R2));
+            for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + (i64)i * (2 * R2));
+        } else {
+            /* the r2r pre-processing as a gather inside the row: v[m] for m = 2j, 2j + 1 */
+            const double *row = src + (i64)at[u] * a.dis[0];
+#pragma unroll
+            for (int i = 0; i < R1; ++i) {
+                const i64 j = aa[u] + R2 * i;
+                x[u][i] = c_make(r2r_pre_elem(a, row, 2 * j), r2r_pre_elem(a, row, 2 * j + 1));
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < QA; ++u) {

@@ -147,7 +147,27 @@ class Interp(object):
                 xr = np.fft.irfft(Y, n=2 * L, axis=0) * (2 * L)
                 _store(dst, doff, s.dst_im, 0, xr[0::2] + 1j * xr[1::2])
                 return
-            x = _load(src, soff, s.src_im, s.flags)
+            if (s.flags & fa.F_R2C_ROWS) and s.aux_buf > 0:
+                # in-row gather of the r2r pre-processing: v[m], m < 2L, from the user's row (stride is_l)
+                mode, N = s.aux_buf, 2 * L
+                n = {fa.R2R_PRE_E00: N // 2 + 1, fa.R2R_PRE_O00: N // 2 - 1}.get(mode, N)
+                row0 = soff - l * s.is_l                              # offset of element 0 of every row
+                m = np.arange(N, dtype=np.int64).reshape([N] + [1] * len(dn))
+                if mode in (fa.R2R_PRE_E10, fa.R2R_PRE_O10):
+                    si = np.where(m < (n + 1) // 2, 2 * m, 2 * n - 1 - 2 * m)
+                    v = src[row0[0:1] + si * s.is_l]
+                    if mode == fa.R2R_PRE_O10:
+                        v = np.where(si & 1, -v, v)
+                elif mode == fa.R2R_PRE_E00:
+                    v = src[row0[0:1] + np.where(m < n, m, 2 * (n - 1) - m) * s.is_l]
+                else:
+                    lo = (m >= 1) & (m <= n)
+                    hi = m > n + 1
+                    v = np.where(lo, src[row0[0:1] + np.where(lo, m - 1, 0) * s.is_l], 0.0) \
+                        - np.where(hi, src[row0[0:1] + np.where(hi, 2 * (n + 1) - m - 1, 0) * s.is_l], 0.0)
+                x = v[0::2] + 1j * v[1::2]
+            else:
+                x = _load(src, soff, s.src_im, s.flags)
             if s.tw_n and (s.flags & fa.F_TW_IN):
                 m = l * twb
                 assert m.max() < s.tw_n
