@@ -58,20 +58,20 @@ struct R2CRArgs {
    the user's row (what the PRE_* modes of r2r_kernel write to scratch):
    N = 2L is the inner length, a.rn the r2r length n */
 template <class A>
-FA_DEV double r2r_pre_elem(const A &a, const double *row, i64 m, i64 stride) {
+FA_DEV double r2r_pre_elem(const A &a, const double *row, i64 m) {
     const i64 n = a.rn;
     switch (a.pre) {
     case FFTW_AMD_R2R_PRE_E10:
     case FFTW_AMD_R2R_PRE_O10: {
         const i64 si = (m < (n + 1) / 2) ? 2 * m : 2 * n - 1 - 2 * m;
-        const double v = row[si * stride];
+        const double v = row[si * a.is_k];
         return (a.pre == FFTW_AMD_R2R_PRE_O10 && (si & 1)) ? -v : v;
     }
     case FFTW_AMD_R2R_PRE_E00:
-        return row[(m < n ? m : 2 * (n - 1) - m) * stride];
+        return row[(m < n ? m : 2 * (n - 1) - m) * a.is_k];
     case FFTW_AMD_R2R_PRE_O00:
-        if (m >= 1 && m <= n) return row[(m - 1) * stride];
-        if (m > n + 1) return -row[(2 * (n + 1) - m - 1) * stride];
+        if (m >= 1 && m <= n) return row[(m - 1) * a.is_k];
+        if (m > n + 1) return -row[(2 * (n + 1) - m - 1) * a.is_k];
         return 0.0;
     default:
         return 0.0;
@@ -115,27 +115,15 @@ r2crows_kernel(const R2CRArgs a) {
             const double *p = src + (i64)at[u] * a.dis[0] + 2 * aa[u];
 #pragma unroll
             for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + (i64)i * (2 * R2));
-        }
-    }
-    if (a.pre != 0) {
-        /* the r2r pre-processing as a gather inside the row: the T user rows are staged in the
-           LDS with coalesced loads, then every item picks v[m], m = 2j and 2j + 1, from there */
-        const int rn = (int)a.rn;
-        for (int e = tid; e < Tcur * rn; e += 256) {
-            const int t = e / rn, m = e - t * rn;
-            plane[t * rn + m] = src[(i64)t * a.dis[0] + (i64)m * a.is_k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < QA; ++u) {
-            const double *row = plane + at[u] * rn;
+        } else {
+            /* the r2r pre-processing as a gather inside the row: v[m] for m = 2j, 2j + 1 */
+            const double *row = src + (i64)at[u] * a.dis[0];
 #pragma unroll
             for (int i = 0; i < R1; ++i) {
                 const i64 j = aa[u] + R2 * i;
-                x[u][i] = c_make(r2r_pre_elem(a, row, 2 * j, 1), r2r_pre_elem(a, row, 2 * j + 1, 1));
+                x[u][i] = c_make(r2r_pre_elem(a, row, 2 * j), r2r_pre_elem(a, row, 2 * j + 1));
             }
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int u = 0; u < QA; ++u) {
