@@ -164,8 +164,11 @@ static plan *finish_locked(plan *p, double *ri, double *ii, double *ro, double *
                             c.small_tiles = st;
                             c.long_first = lf;
                             q = clone_problem(p, c);
-                            if (!q || fa_build(q)) { fa_plan_free(q); continue; }
+                            if (!q) continue;
+                            /* the builder looks at the arrays (alignment, aliasing) */
                             q->ri = ri; q->ii = ii; q->ro = ro; q->io = io;
+                            q->inplace = p->inplace;
+                            if (fa_build(q)) { fa_plan_free(q); continue; }
                             q->in_lo = p->in_lo; q->in_hi = p->in_hi; q->out_lo = p->out_lo; q->out_hi = p->out_hi;
                             q->out_written = p->out_written;
                             fa_run(q, ri, ii, ro, io);          /* warm-up, device init */

@@ -958,9 +958,24 @@ static int axis_pass_count(i64 n) {
 /* the fused rows kernel loads 16-byte pairs and stores 16-byte complex numbers: every
    loop stride must keep that alignment, the user arrays must be 16-byte aligned, there must
    be a loop to tile over, and the tile dim must not be a two-level (pair) dim */
+/* Do source and destination of a one-trip rows step alias?  The fused rows kernels read a tile
+   of rows and write the same tile's results without a scratch image in between, so when both
+   sides are the same user memory every row must map onto itself (FFTW's padded in-place
+   layout does); otherwise the general path, which reads a whole chunk into scratch first. */
+static int rows_alias_ok(const plan *p, const fa_axis *ax, fa_loc a, fa_loc b) {
+    int j, same_mem = (a.buf == b.buf && a.buf < 2) ||
+                      (a.buf < 2 && b.buf < 2 && (void *)p->ri == (void *)p->ro && p->ri != NULL);
+    if (!same_mem) return 1;
+    if (a.base != b.base) return 0;
+    for (j = 0; j < ax->nloops; ++j)
+        if (ax->loops[j].n > 1 && ax->loops[j].is != ax->loops[j].os) return 0;
+    return 1;
+}
+
 static int r2c_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc in, fa_loc out, int epi, int pre) {
     int j, rows = 0;
     if (getenv("FFTW_AMD_NO_R2CROWS")) return 0;
+    if (!rows_alias_ok(p, ax, in, out)) return 0;
     for (j = 0; j < ax->nloops; ++j) {
         if ((!pre && (ax->loops[j].is % 2)) || (!epi && (ax->loops[j].os % 2))) return 0;
         /* emit_pass would fold such a loop into a two-level tile dim, which this kernel lacks */
@@ -977,6 +992,7 @@ static int r2c_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc in, fa_lo
 static int c2r_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc cur, fa_loc out, int pro) {
     int j, rows = 0;
     if (getenv("FFTW_AMD_NO_R2CROWS")) return 0;
+    if (!rows_alias_ok(p, ax, cur, out)) return 0;
     for (j = 0; j < ax->nloops; ++j) {
         if ((!pro && (ax->loops[j].is % 2)) || (ax->loops[j].os % 2)) return 0;
         if (ax->loops[j].n == 2 && (iabs(ax->loops[j].is) == 2 || iabs(ax->loops[j].os) == 2)) return 0;
