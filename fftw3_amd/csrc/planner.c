@@ -963,7 +963,11 @@ static int axis_pass_count(i64 n) {
    sides are the same user memory every row must map onto itself (FFTW's padded in-place
    layout does); otherwise the general path, which reads a whole chunk into scratch first. */
 static int rows_alias_ok(const plan *p, const fa_axis *ax, fa_loc a, fa_loc b) {
-    int j, same_mem = (a.buf == b.buf && a.buf < 2) ||
+    int j, same_mem;
+    /* FFTW_UNALIGNED: the plan must serve arrays of any alignment through the new-array
+       interface; the rows kernels rely on 16-byte alignment and have no fallback */
+    if (p->flags & FFTW_UNALIGNED) return 0;
+    same_mem = (a.buf == b.buf && a.buf < 2) ||
                       (a.buf < 2 && b.buf < 2 && (void *)p->ri == (void *)p->ro && p->ri != NULL);
     if (!same_mem) return 1;
     if (a.base != b.base) return 0;
