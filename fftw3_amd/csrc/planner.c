@@ -1567,11 +1567,7 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
     if (inner == IN_R2C && post && r2r_can_fuse(N)) { fuse_post = 1; cntB = 0; }
     /* short rows: the fused real-rows kernel also gathers the pre-processed sequence from the
        user's row itself -- the whole r2r axis is one trip */
-    /* (measured, tests/perf_r2r_rows.py: the stride-2 gather of the DCT-II / DST-II shuffle pays
-       up to 512 points -- 256: 1.10 -> 0.87 ms per GiB -- beyond that the separate shuffle step
-       is faster, 1024: 1.00 vs 1.26 ms; the extensions of DCT-I / DST-I gather contiguously) */
-    if (fuse_post && pre && pre != FFTW_AMD_R2R_PRE_HC2R && fa_hip_r2c_rows_tile((int)(N / 2)) > 0 &&
-        !((pre == FFTW_AMD_R2R_PRE_E10 || pre == FFTW_AMD_R2R_PRE_O10) && N > 512)) {
+    if (fuse_post && pre && pre != FFTW_AMD_R2R_PRE_HC2R && fa_hip_r2c_rows_tile((int)(N / 2)) > 0) {
         fa_axis tax = *axp;
         if (r2c_rows_layout_ok(p, &tax, in, out, post, pre)) { rows_pre = pre; cntA = 0; }
     }

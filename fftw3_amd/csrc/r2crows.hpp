@@ -30,7 +30,9 @@ template <int R1, int R2> struct R2CRGeom {
     static constexpr int ST = R1 * SA + ((R1 * SA) % 2 == 0 ? 1 : 0);
     static constexpr int SX = L + 1;                               /* Z planes: row stride */
     static constexpr int EX = T * ST;
-    static constexpr int lds_doubles = (EX > 2 * T * SX ? EX : 2 * T * SX) + 16;
+    static constexpr int SQ = L / 2 + 1;                           /* DCT-II staging: stride of a residue class */
+    static constexpr int fa_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+    static constexpr int lds_doubles = fa_max3(EX, 2 * T * SX, T * 4 * SQ) + 16;
 };
 
 #include "r2r_epi.hpp"
@@ -115,6 +117,8 @@ r2crows_kernel(const R2CRArgs a) {
             const double *p = src + (i64)at[u] * a.dis[0] + 2 * aa[u];
 #pragma unroll
             for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + (i64)i * (2 * R2));
+        } else if (a.pre == FFTW_AMD_R2R_PRE_E10 || a.pre == FFTW_AMD_R2R_PRE_O10) {
+            /* filled below from the LDS staging */
         } else {
             /* the r2r pre-processing as a gather inside the row: v[m] for m = 2j, 2j + 1 */
             const double *row = src + (i64)at[u] * a.dis[0];
@@ -124,6 +128,31 @@ r2crows_kernel(const R2CRArgs a) {
                 x[u][i] = c_make(r2r_pre_elem(a, row, 2 * j), r2r_pre_elem(a, row, 2 * j + 1));
             }
         }
+    }
+    if (a.pre == FFTW_AMD_R2R_PRE_E10 || a.pre == FFTW_AMD_R2R_PRE_O10) {
+        /* DCT-II / DST-II shuffle v[m] = x[2m] (m < n/2), x[2n-1-2m] (else), n = 2L: the T rows
+           are staged in the LDS with coalesced loads, split into the four residue classes of the
+           source index mod 4 -- then each of the four streams an item gathers (4j, 4j+2 in the
+           first half, 2n-1-4j, 2n-3-4j in the second) is contiguous across the lanes */
+        constexpr int SQ = G::SQ, RS = 4 * G::SQ;
+        constexpr int N2 = 2 * L;
+        for (int e = tid; e < Tcur * N2; e += 256) {
+            const int t = e / N2, m = e - t * N2;
+            plane[t * RS + (m & 3) * SQ + (m >> 2)] = src[(i64)t * a.dis[0] + (i64)m * a.is_k];
+        }
+        __syncthreads();
+        const double sgn = (a.pre == FFTW_AMD_R2R_PRE_O10) ? -1.0 : 1.0;
+#pragma unroll
+        for (int u = 0; u < QA; ++u) {
+            const double *row = plane + at[u] * RS;
+#pragma unroll
+            for (int i = 0; i < R1; ++i) {
+                const int j = aa[u] + R2 * i;              /* pair index: v[2j], v[2j+1] */
+                if (j < L / 2) x[u][i] = c_make(row[j], row[2 * SQ + j]);
+                else x[u][i] = c_make(sgn * row[3 * SQ + (L - 1 - j)], sgn * row[SQ + (L - 1 - j)]);
+            }
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int u = 0; u < QA; ++u) {
