@@ -136,9 +136,26 @@ r2crows_kernel(const R2CRArgs a) {
            first half, 2n-1-4j, 2n-3-4j in the second) is contiguous across the lanes */
         constexpr int SQ = G::SQ, RS = 4 * G::SQ;
         constexpr int N2 = 2 * L;
-        for (int e = tid; e < Tcur * N2; e += 256) {
-            const int t = e / N2, m = e - t * N2;
-            plane[t * RS + (m & 3) * SQ + (m >> 2)] = src[(i64)t * a.dis[0] + (i64)m * a.is_k];
+        {
+            /* T * 2L = 8192 reals per tile: 32 independent loads per item, then the LDS writes */
+            constexpr int NR = (T * N2) / 256;
+            double stg[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int e = r * 256 + tid;
+                int t = e / N2;
+                const int m = e - t * N2;
+                t = t < Tcur - 1 ? t : Tcur - 1;
+                stg[r] = src[(i64)t * a.dis[0] + (i64)m * a.is_k];
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int e = r * 256 + tid;
+                int t = e / N2;
+                const int m = e - t * N2;
+                t = t < Tcur - 1 ? t : Tcur - 1;
+                plane[t * RS + (m & 3) * SQ + (m >> 2)] = stg[r];
+            }
         }
         __syncthreads();
         const double sgn = (a.pre == FFTW_AMD_R2R_PRE_O10) ? -1.0 : 1.0;
