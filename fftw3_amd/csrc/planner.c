@@ -1727,6 +1727,16 @@ int fa_build(plan *p) {
         plan_reset_build(p);
         build_steps(p);
         if (p->failed) return -1;
+        /* a plan can turn out scratch-free only once the batch loop has more than one entry
+           (the fused rows kernels need rows to tile over): then nothing limits the chunk */
+        per_elem = 0;
+        for (i = 2; i < p->nbufs; ++i) per_elem += p->buf_reals[i];
+        if (per_elem == 0 && p->chunk != p->batch) {
+            p->chunk = p->batch;
+            plan_reset_build(p);
+            build_steps(p);
+            if (p->failed) return -1;
+        }
     }
     return 0;
 }
