@@ -212,7 +212,8 @@ int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *co
     const bool fwd = (d->flags & FFTW_AMD_F_R2C_ROWS) != 0;
     const int epi = (int)d->aux_valid;                 /* fused r2r epilogue (r2c) / prologue (c2r), or 0 */
     const int pre = (fwd && d->aux_buf > 0) ? d->aux_buf : 0;   /* in-row gather of the r2r pre-processing */
-    const bool real_src = (!fwd && epi) || pre, real_dst = fwd && epi;
+    const int post = (!fwd && d->aux_buf > 0) ? d->aux_buf : 0; /* output shuffle in the c2r rows store */
+    const bool real_src = (!fwd && epi) || pre, real_dst = (fwd && epi) || post;
     if (T <= 0 || d->tile != T || (!real_src && (d->src_im != 1 || d->is_l != 2)) ||
         (!real_dst && (d->dst_im != 1 || d->os_l != 2))) {
         fprintf(stderr, "fftw3_amd: internal error: fused r2c rows step with an unsupported layout\n");
@@ -237,6 +238,7 @@ int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *co
     ra.flags = 0;
     ra.r2r = epi;
     ra.pre = pre;
+    ra.post = post;
     ra.twmul = (epi && d->aux_base > 0) ? (int)d->aux_base : 1;
     ra.rn = epi == FFTW_AMD_R2R_POST_E00 ? d->aux_n / 2 + 1 : (epi == FFTW_AMD_R2R_POST_O00 ? d->aux_n / 2 - 1 : d->aux_n);
     if ((!real_src && ((uintptr_t)ra.src % 16)) || (!real_dst && ((uintptr_t)ra.dst % 16))) {

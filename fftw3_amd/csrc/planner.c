@@ -993,19 +993,19 @@ static int r2c_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc in, fa_lo
     return 1;
 }
 
-static int c2r_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc cur, fa_loc out, int pro) {
+static int c2r_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc cur, fa_loc out, int pro, int post) {
     int j, rows = 0;
     if (getenv("FFTW_AMD_NO_R2CROWS")) return 0;
     if (!rows_alias_ok(p, ax, cur, out)) return 0;
     for (j = 0; j < ax->nloops; ++j) {
-        if ((!pro && (ax->loops[j].is % 2)) || (ax->loops[j].os % 2)) return 0;
+        if ((!pro && (ax->loops[j].is % 2)) || (!post && (ax->loops[j].os % 2))) return 0;
         if (ax->loops[j].n == 2 && (iabs(ax->loops[j].is) == 2 || iabs(ax->loops[j].os) == 2)) return 0;
         if (ax->loops[j].n > 1) rows = 1;
     }
     if (!rows) return 0;
     if (!pro && cur.buf == 0 && (((size_t)p->ri % 16) || (cur.base % 2))) return 0;
     if (!pro && cur.buf == 1 && (((size_t)p->ro % 16) || (cur.base % 2))) return 0;
-    if (out.buf == 1 && (((size_t)p->ro % 16) || (out.base % 2))) return 0;
+    if (!post && out.buf == 1 && (((size_t)p->ro % 16) || (out.base % 2))) return 0;
     return 1;
 }
 
@@ -1232,7 +1232,7 @@ static void build_r2c(plan *p) {
    that prologue while loading (even lengths only, see r2r_can_fuse)
    ps / pim: pair geometry of the real output, as in emit_r2c_axis */
 static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 cs, fa_loc out, i64 rs, int pro,
-                          i64 ps, i64 pim) {
+                          i64 ps, i64 pim, int post) {
     fa_axis ax = *axp;
     int j;
     if (ps == 0) { ps = 2 * rs; pim = rs; }
@@ -1285,8 +1285,9 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         for (j = 0; j < q_ax.nloops; ++j) q_ax.loops[j].is = lts[j];
         fa_emit_axis(p, &q_ax);
         buf_release(p, zbuf);
-    } else if (nl % 2 == 0 && nl >= 2 && ps == 2 && pim == 1 && (pro != 0 || (cs == 2 && cur.im == 1)) &&
-               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && c2r_rows_layout_ok(p, &ax, cur, out, pro)) {
+    } else if (nl % 2 == 0 && nl >= 2 && (post != 0 || (ps == 2 && pim == 1)) &&
+               (pro != 0 || (cs == 2 && cur.im == 1)) &&
+               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && c2r_rows_layout_ok(p, &ax, cur, out, pro, post)) {
         /* contiguous rows of a supported length: tangle + backward half-length DFT in ONE trip */
         sdim d[FA_MAXLOOPS];
         int nd = 0;
@@ -1297,9 +1298,10 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
             d[nd].n = ax.loops[j].n; d[nd].is = ax.loops[j].is; d[nd].os = ax.loops[j].os;
             d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
         }
-        emit_pass(p, cur, dstp, nl / 2, pro ? cs : 2, 2, d, nd, 0, FFTW_AMD_F_C2R_ROWS);
+        emit_pass(p, cur, dstp, nl / 2, pro ? cs : 2, post ? rs : 2, d, nd, 0, FFTW_AMD_F_C2R_ROWS);
         s = &p->steps[p->nsteps - 1];
         s->variant = FFTW_AMD_K_C2R;
+        s->aux_buf = post ? post : -1;   /* r2r output shuffle done by the kernel's store (FFTW_AMD_R2R_POST_E01 / O01) */
         s->tile = fa_hip_r2c_rows_tile((int)(nl / 2));
         s->tile_lo_n = 1;
         s->aux_n = nl;              /* as in the r2c rows step: n, fused r2r prologue, twiddle multiplier */
@@ -1453,7 +1455,7 @@ static void build_c2r(plan *p) {
         if (collect_loops(&view, td, r, r - 1, NULL, 0, &ax)) { p->failed = 1; return; }
     }
 
-    emit_c2r_axis(p, nl, &ax, cur, cdims[r - 1].is, out, p->dims[r - 1].os, 0, 0, 0);
+    emit_c2r_axis(p, nl, &ax, cur, cdims[r - 1].is, out, p->dims[r - 1].os, 0, 0, 0, 0);
     if (cbuf >= 0) buf_release(p, cbuf);
 }
 
@@ -1501,7 +1503,7 @@ static fftw_amd_step_desc *emit_r2r_step(plan *p, int mode, i64 n, i64 K, i64 tw
 static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc in, i64 rs,
                           fa_loc out, i64 os) {
     enum { IN_R2C, IN_C2R, IN_C2C };
-    int pre = 0, post = 0, inner = IN_R2C, j, nl = axp->nloops, fuse_pre = 0, fuse_post = 0, rows_pre = 0;
+    int pre = 0, post = 0, inner = IN_R2C, j, nl = axp->nloops, fuse_pre = 0, fuse_post = 0, rows_pre = 0, rows_post = 0;
     i64 N = n, cntA = 0, unitA = 1, cntB = 0, unitB = 1, twmod = 0, Kpre = 0, Kpost = 0;
     i64 lis_user[FA_MAXLOOPS], los_user[FA_MAXLOOPS], ltsA[FA_MAXLOOPS], ltsB[FA_MAXLOOPS];
     i64 tsA = 0, tsB = 0, psA = 0, pimA = 0, psB = 0, pimB = 0;
@@ -1572,6 +1574,11 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
         if (r2c_rows_layout_ok(p, &tax, in, out, post, pre)) { rows_pre = pre; cntA = 0; }
     }
     if (inner == IN_C2R && pre && r2r_can_fuse(N)) { fuse_pre = 1; cntA = 0; }
+    /* short rows: the fused c2r rows kernel also does the DCT-III / DST-III output shuffle */
+    if (fuse_pre && post && fa_hip_r2c_rows_tile((int)(N / 2)) > 0) {
+        fa_axis tax = *axp;
+        if (c2r_rows_layout_ok(p, &tax, in, out, pre, post)) { rows_post = post; cntB = 0; }
+    }
 
     /* Real scratch sequences of even length are laid out as adjacent pairs
        (sample 2j, 2j+1) = one interleaved complex number of stride ts: whatever loops end
@@ -1641,8 +1648,12 @@ static void emit_r2r_axis(plan *p, int kind, i64 n, const fa_axis *axp, fa_loc i
             iax.loops[j].os = post ? ltsB[j] : los_user[j];
         }
         d.im = 0;
-        if (fuse_pre) emit_c2r_axis(p, N, &iax, in, rs, d, post ? pimB : os, pre, post ? psB : 0, post ? pimB : 0);
-        else emit_c2r_axis(p, N, &iax, A, tsA, d, post ? pimB : os, 0, post ? psB : 0, post ? pimB : 0);
+        if (rows_post) {
+            for (j = 0; j < nl; ++j) iax.loops[j].os = los_user[j];
+            emit_c2r_axis(p, N, &iax, in, rs, out, os, pre, 0, 0, rows_post);
+            post = 0;
+        } else if (fuse_pre) emit_c2r_axis(p, N, &iax, in, rs, d, post ? pimB : os, pre, post ? psB : 0, post ? pimB : 0, 0);
+        else emit_c2r_axis(p, N, &iax, A, tsA, d, post ? pimB : os, 0, post ? psB : 0, post ? pimB : 0, 0);
     } else {
         for (j = 0; j < nl; ++j) { iax.loops[j].is = ltsA[j]; iax.loops[j].os = ltsA[j]; }
         iax.n = N; iax.is = tsA; iax.os = tsA;
@@ -2093,7 +2104,7 @@ char *fa_sprint(const plan *p) {
                (pass1024 / passrr / pass3s), lds = runtime-radix LDS kernel + its radices */
             len += (size_t)snprintf(s + len, cap - len, "-%d/", d->L);
             if (d->variant == FFTW_AMD_K_R2C) len += (size_t)snprintf(s + len, cap - len, d->aux_valid ? "r2c-rows+r2r-post" : "r2c-rows");
-            else if (d->variant == FFTW_AMD_K_C2R) len += (size_t)snprintf(s + len, cap - len, d->aux_valid ? "c2r-rows+r2r-pre" : "c2r-rows");
+            else if (d->variant == FFTW_AMD_K_C2R) len += (size_t)snprintf(s + len, cap - len, d->aux_valid ? (d->aux_buf > 0 ? "c2r-rows+r2r-pre+post" : "c2r-rows+r2r-pre") : "c2r-rows");
             else if (d->variant == FFTW_AMD_K_P1024) len += (size_t)snprintf(s + len, cap - len, "reg32x32");
             else if (d->variant == FFTW_AMD_K_RR) len += (size_t)snprintf(s + len, cap - len, "reg2");
             else if (d->variant == FFTW_AMD_K_R3) len += (size_t)snprintf(s + len, cap - len, "reg3");

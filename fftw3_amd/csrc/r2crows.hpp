@@ -45,6 +45,8 @@ struct R2CRArgs {
     i64 is_k, src_im;       /* prologue addressing (pro_load, c2r side) */
     i64 rn;                 /* r2r length */
     int r2r, twmul, flags;  /* FFTW_AMD_R2R_POST_* or 0; untangle twiddle = table entry k * twmul */
+    int post;               /* c2r rows: FFTW_AMD_R2R_POST_E01 / O01 = store y[2j] = v[j], y[2j+1] = +-v[n-1-j]
+                               (reals of stride os_k) instead of the plain real pairs; 0 = plain */
     int pre;                /* r2c rows: FFTW_AMD_R2R_PRE_E10 / O10 / E00 / O00 = gather the real sequence from the
                                user's r2r input (element stride is_k) instead of loading pairs; 0 = plain */
     i64 dn[FFTW_AMD_MAX_DIMS], dis[FFTW_AMD_MAX_DIMS], dos[FFTW_AMD_MAX_DIMS];
@@ -376,14 +378,46 @@ c2rrows_kernel(const R2CRArgs a) {
         for (int q = 0; q < R2; ++q) y[v][q].y = plane[bt[v] * ST + bd[v] * SA + q];
 
     /* ---- stage B, store the pair (x[2j], x[2j+1]) = (Im, Re) of the swapped result */
+    if (a.post == 0) {
+#pragma unroll
+        for (int v = 0; v < QB; ++v) {
+            RB<R2>::run(y[v]);
+            double *p = dst + (i64)bt[v] * a.dos[0] + 2 * bd[v];
+#pragma unroll
+            for (int c = 0; c < R2; ++c) {
+                const cplx w = y[v][RB<R2>::slot(c)];
+                *reinterpret_cast<cplx *>(p + (i64)c * (2 * R1)) = c_make(w.y, w.x);
+            }
+        }
+        return;
+    }
+    /* ---- DCT-III / DST-III output shuffle y[2j] = v[j], y[2j+1] = +-v[n-1-j] (n = 2L): the real
+       rows v go to the LDS, then coalesced stores read the two interleaved streams back */
+    constexpr int N2 = 2 * L, SV = 2 * L + 2;
+    __syncthreads();
 #pragma unroll
     for (int v = 0; v < QB; ++v) {
         RB<R2>::run(y[v]);
-        double *p = dst + (i64)bt[v] * a.dos[0] + 2 * bd[v];
 #pragma unroll
         for (int c = 0; c < R2; ++c) {
             const cplx w = y[v][RB<R2>::slot(c)];
-            *reinterpret_cast<cplx *>(p + (i64)c * (2 * R1)) = c_make(w.y, w.x);
+            const int k = bd[v] + R1 * c;
+            plane[bt[v] * SV + 2 * k] = w.y;
+            plane[bt[v] * SV + 2 * k + 1] = w.x;
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int NR = (T * N2) / 256;
+        const double sgn = (a.post == FFTW_AMD_R2R_POST_O01) ? -1.0 : 1.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int e = r * 256 + tid;
+            int t = e / N2;
+            const int q = e - t * N2;
+            t = t < Tcur - 1 ? t : Tcur - 1;
+            const double val = (q & 1) ? sgn * plane[t * SV + (N2 - 1 - (q >> 1))] : plane[t * SV + (q >> 1)];
+            dst[(i64)t * a.dos[0] + (i64)q * a.os_k] = val;
         }
     }
 }

@@ -145,6 +145,18 @@ class Interp(object):
                 Y[0] = Y[0].real
                 Y[L] = Y[L].real
                 xr = np.fft.irfft(Y, n=2 * L, axis=0) * (2 * L)
+                if s.aux_buf > 0:
+                    # DCT-III / DST-III output shuffle done by the store: y[2j] = v[j], y[2j+1] = +-v[n-1-j]
+                    N = 2 * L
+                    yy = np.empty_like(xr)
+                    yy[0::2] = xr[:L]
+                    yy[1::2] = xr[::-1][:L] * (-1.0 if s.aux_buf == fa.R2R_POST_O01 else 1.0)
+                    g3 = _grids([N] + dn)
+                    do3 = dbase + g3[0] * s.os_l
+                    for i, gi in enumerate(g3[1:]):
+                        do3 = do3 + gi * dos[i]
+                    dst[np.broadcast_to(do3, yy.shape)] = yy
+                    return
                 _store(dst, doff, s.dst_im, 0, xr[0::2] + 1j * xr[1::2])
                 return
             if (s.flags & fa.F_R2C_ROWS) and s.aux_buf > 0:

@@ -581,3 +581,52 @@ def test_gpu_r2r_fused_rows_prologues(kind, n):
     p.execute()
     p.sync()
     assert aerror(dx.cpu().numpy(), oracle_r2r(x, shape, kinds, howmany=2)) <= TOL
+
+
+@pytest.mark.parametrize("kind,n", [(fa.REDFT01, 1024), (fa.RODFT01, 512), (fa.REDFT01, 128)])
+def test_planner_r2r_rows_store_shuffle(kind, n):
+    """DCT-III / DST-III short rows: one fused launch (prologue, backward pass, output shuffle in the
+    store); checked through the numpy step interpreter, also with a strided destination"""
+    from step_interp import run_plan_on_host
+    rng = np.random.default_rng(n + kind)
+    hm = 5
+    x = rrand(rng, hm * n)
+    y = np.zeros(hm * n)
+    p = fa.plan_many_r2r(1, [n], hm, x, None, 1, n, y, None, 1, n, [kind])
+    assert "c2r-rows+r2r-pre+post" in p.sprint() and len(p.steps()) == 1, p.sprint()
+    run_plan_on_host(p, x, y)
+    assert aerror(y, oracle_r2r(x, [n], [kind], howmany=hm)) <= TOL
+    y = np.zeros(3 * hm * n)
+    p = fa.plan_many_r2r(1, [n], hm, x, None, 1, n, y, None, 3, 3 * n, [kind])
+    assert "c2r-rows+r2r-pre+post" in p.sprint(), p.sprint()
+    run_plan_on_host(p, x, y)
+    assert aerror(y[::3], oracle_r2r(x, [n], [kind], howmany=hm)) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", [(fa.REDFT01, 1024), (fa.RODFT01, 2048), (fa.REDFT01, 128), (fa.RODFT01, 256)])
+def test_gpu_r2r_rows_store_shuffle(kind, n):
+    """the fused c2r rows kernel also does the DCT-III / DST-III output shuffle: ragged batch,
+    in place, strided destination"""
+    import torch
+    rng = np.random.default_rng(n + kind)
+    hm = 37
+    x = rrand(rng, hm * n)
+    dx = _dev(x)
+    dy = torch.zeros_like(dx)
+    p = fa.plan_many_r2r(1, [n], hm, dx, None, 1, n, dy, None, 1, n, [kind])
+    assert "c2r-rows+r2r-pre+post" in p.sprint(), p.sprint()
+    p.execute()
+    p.sync()
+    want = oracle_r2r(x, [n], [kind], howmany=hm)
+    assert aerror(dy.cpu().numpy(), want) <= TOL
+    assert np.array_equal(dx.cpu().numpy(), x)
+    dz = torch.zeros(3 * hm * n, dtype=torch.float64, device="cuda")
+    p = fa.plan_many_r2r(1, [n], hm, dx, None, 1, n, dz, None, 3, 3 * n, [kind])
+    p.execute()
+    p.sync()
+    assert aerror(dz.cpu().numpy()[::3], want) <= TOL
+    p = fa.plan_many_r2r(1, [n], hm, dx, None, 1, n, dx, None, 1, n, [kind])      # in place
+    p.execute()
+    p.sync()
+    assert aerror(dx.cpu().numpy(), want) <= TOL
