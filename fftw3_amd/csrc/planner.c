@@ -15,6 +15,7 @@
  * decomposition is a function of n and of which index is contiguous.
  */
 #include <math.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -2088,33 +2089,48 @@ static const char *kind_name(int k) {
     return "?";
 }
 
+/* bounded append: never writes past cap, whatever the numbers print to */
+static void sapp(char *s, size_t cap, size_t *len, const char *fmt, ...) {
+    va_list ap;
+    int w;
+    if (*len + 1 >= cap) return;
+    va_start(ap, fmt);
+    w = vsnprintf(s + *len, cap - *len, fmt, ap);
+    va_end(ap);
+    if (w < 0) return;
+    *len += (size_t)w;
+    if (*len >= cap) *len = cap - 1;
+}
+
 /* lisp-like dump in the spirit of the reference's fftw_print_plan
    (fftw/fftw_api.c:1046-1080) */
 char *fa_sprint(const plan *p) {
-    size_t cap = 256 + (size_t)p->nsteps * 256, len = 0;
+    size_t cap = 256 + (size_t)p->nsteps * 512, len = 0;
     char *s = (char *)malloc(cap);
+    if (!s) return NULL;
+    s[0] = 0;
     int i, j;
     const char *tn = p->type == FA_C2C ? "dft" : p->type == FA_R2C ? "rdft2-r2c" : p->type == FA_C2R ? "rdft2-c2r" : "rdft-r2r";
-    len += (size_t)snprintf(s + len, cap - len, "(hip-%s batch=%lld chunk=%lld", tn, p->batch, p->chunk);
+    sapp(s, cap, &len, "(hip-%s batch=%lld chunk=%lld", tn, p->batch, p->chunk);
     for (i = 0; i < p->nsteps; ++i) {
         const fftw_amd_step_desc *d = &p->steps[i];
-        len += (size_t)snprintf(s + len, cap - len, "\n  (%s", kind_name(d->kind));
+        sapp(s, cap, &len, "\n  (%s", kind_name(d->kind));
         if (d->kind == FFTW_AMD_STEP_PASS) {
             /* which kernel runs the pass: reg32x32 / reg2 / reg3 = register-resident
                (pass1024 / passrr / pass3s), lds = runtime-radix LDS kernel + its radices */
-            len += (size_t)snprintf(s + len, cap - len, "-%d/", d->L);
-            if (d->variant == FFTW_AMD_K_R2C) len += (size_t)snprintf(s + len, cap - len, d->aux_valid ? "r2c-rows+r2r-post" : "r2c-rows");
-            else if (d->variant == FFTW_AMD_K_C2R) len += (size_t)snprintf(s + len, cap - len, d->aux_valid ? (d->aux_buf > 0 ? "c2r-rows+r2r-pre+post" : "c2r-rows+r2r-pre") : "c2r-rows");
-            else if (d->variant == FFTW_AMD_K_P1024) len += (size_t)snprintf(s + len, cap - len, "reg32x32");
-            else if (d->variant == FFTW_AMD_K_RR) len += (size_t)snprintf(s + len, cap - len, "reg2");
-            else if (d->variant == FFTW_AMD_K_R3) len += (size_t)snprintf(s + len, cap - len, "reg3");
+            sapp(s, cap, &len, "-%d/", d->L);
+            if (d->variant == FFTW_AMD_K_R2C) sapp(s, cap, &len, d->aux_valid ? "r2c-rows+r2r-post" : "r2c-rows");
+            else if (d->variant == FFTW_AMD_K_C2R) sapp(s, cap, &len, d->aux_valid ? (d->aux_buf > 0 ? "c2r-rows+r2r-pre+post" : "c2r-rows+r2r-pre") : "c2r-rows");
+            else if (d->variant == FFTW_AMD_K_P1024) sapp(s, cap, &len, "reg32x32");
+            else if (d->variant == FFTW_AMD_K_RR) sapp(s, cap, &len, "reg2");
+            else if (d->variant == FFTW_AMD_K_R3) sapp(s, cap, &len, "reg3");
             else {
-                len += (size_t)snprintf(s + len, cap - len, "lds:");
+                sapp(s, cap, &len, "lds:");
                 for (j = 0; j < d->nradices; ++j)
-                    len += (size_t)snprintf(s + len, cap - len, "%s%d", j ? "x" : "", d->radices[j]);
+                    sapp(s, cap, &len, "%s%d", j ? "x" : "", d->radices[j]);
             }
-            len += (size_t)snprintf(s + len, cap - len, " tile=%d", d->tile);
-            if (d->tw_n) len += (size_t)snprintf(s + len, cap - len, " tw=%lld", d->tw_n);
+            sapp(s, cap, &len, " tile=%d", d->tile);
+            if (d->tw_n) sapp(s, cap, &len, " tw=%lld", d->tw_n);
         } else if (d->kind == FFTW_AMD_STEP_R2R ||
                    ((d->kind == FFTW_AMD_STEP_R2C_POST || d->kind == FFTW_AMD_STEP_R2C_POST4 ||
                      d->kind == FFTW_AMD_STEP_C2R_PRE || d->kind == FFTW_AMD_STEP_C2R_PRE4) && d->variant)) {
@@ -2124,16 +2140,16 @@ char *fa_sprint(const plan *p) {
                 "post-e10", "post-o10", "post-e01", "post-o01", "post-e00", "post-o00", "post-e11",
                 "post-o11", "post-e11odd", "post-o11odd" };
             int m = (d->variant >= 1 && d->variant <= FFTW_AMD_R2R_POST_O11ODD) ? d->variant : 0;
-            len += (size_t)snprintf(s + len, cap - len, "%s%s n=%lld", d->kind == FFTW_AMD_STEP_R2R ? "-" : "+r2r-",
+            sapp(s, cap, &len, "%s%s n=%lld", d->kind == FFTW_AMD_STEP_R2R ? "-" : "+r2r-",
                                     mn[m], d->aux_n);
         } else {
-            len += (size_t)snprintf(s + len, cap - len, " n=%lld", d->aux_n);
+            sapp(s, cap, &len, " n=%lld", d->aux_n);
         }
-        len += (size_t)snprintf(s + len, cap - len, " buf%d->buf%d x", d->src_buf, d->dst_buf);
+        sapp(s, cap, &len, " buf%d->buf%d x", d->src_buf, d->dst_buf);
         for (j = 0; j < d->ndims; ++j)
-            len += (size_t)snprintf(s + len, cap - len, "%s%lld", j ? "," : "", d->dim_n[j]);
-        len += (size_t)snprintf(s + len, cap - len, ")");
+            sapp(s, cap, &len, "%s%lld", j ? "," : "", d->dim_n[j]);
+        sapp(s, cap, &len, ")");
     }
-    len += (size_t)snprintf(s + len, cap - len, ")");
+    sapp(s, cap, &len, ")");
     return s;
 }
