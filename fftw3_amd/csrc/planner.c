@@ -758,6 +758,38 @@ static int has_register_kernel(i64 L) {
     return L == 1024 || (L <= 1024 && (fa_hip_rr_tile((int)L) > 0 || fa_hip_r3t_tile((int)L) > 0));
 }
 
+/* Three-pass split of a contiguous power of two (n >= 2^21).  The balanced split is not the
+   fastest: per-pass times differ by position (first: long input stride; middle: in place at a
+   medium stride; last: contiguous rows in, transposed out) and by tile width -- the 256-point
+   kernel (16-wide tiles) is the slow one in the first two positions, short middle passes with
+   64 ... 256-wide tiles the fast ones.  Costs: ms per 4 GiB moved, measured on MI355X
+   (tests/perf_p512.py); unmeasured positions carry a pessimistic guess. */
+static void pow2_three_pass_split(i64 n, i64 *lens) {
+    /*                              2^4   2^5   2^6   2^7   2^8   2^9   2^10 */
+    static const double c_first[] = { 1.00, 1.00, 0.95, 0.80, 1.02, 0.87, 1.30 };
+    static const double c_mid[]   = { 0.77, 0.78, 0.75, 0.76, 0.99, 1.05, 1.20 };
+    static const double c_last[]  = { 0.95, 0.95, 0.90, 0.80, 0.80, 0.82, 0.84 };
+    int e = 0, a, m, c, ba = 0, bm = 0, bc = 0;
+    double best = 1e30;
+    while (((i64)1 << e) < n) ++e;
+    for (a = 4; a <= 10; ++a)
+        for (m = 4; m <= 10; ++m) {
+            double t;
+            c = e - a - m;
+            if (c < 4 || c > 10) continue;
+            t = c_first[a - 4] + c_mid[m - 4] + c_last[c - 4];
+            {   /* near-ties go to the more balanced split */
+                int hi = a > m ? (a > c ? a : c) : (m > c ? m : c), lo = a < m ? (a < c ? a : c) : (m < c ? m : c);
+                t += 0.01 * (hi - lo);
+            }
+            if (t < best - 1e-9) { best = t; ba = a; bm = m; bc = c; }
+        }
+    if (!ba) return;
+    lens[0] = (i64)1 << ba;
+    lens[1] = (i64)1 << bm;
+    lens[2] = (i64)1 << bc;
+}
+
 static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     fa_axis ax = *ax_in;
     i64 lens[FA_MAXPASS];
@@ -806,6 +838,7 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     }
     k = fa_factor_passes_pref(ax.n, FA_MAXPASS, lmax1, contiguous ? p->cfg.lmax_multi : FA_TILE_ELEMS / 8, lens,
                               getenv("FFTW_AMD_NO_TUNED") ? NULL : has_register_kernel);
+    if (k == 3 && contiguous && (ax.n & (ax.n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) pow2_three_pass_split(ax.n, lens);
     {
         /* test hook: FFTW_AMD_FORCE_LENS="L1,L2,..." fixes the split of the axis whose length
            is the product (tests/test_gpu_menu.py reaches every kernel variant with it) */
