@@ -6,8 +6,8 @@ import fftw3_amd as fa
 import ast
 CASES = ast.literal_eval(os.environ.get("CASES", "[(17, None), (18, None), (19, None)]"))
 for k, force in CASES:
-    n = 1 << k
-    hm = (1 << 27) // n
+    n = (1 << k) if k < 64 else k
+    hm = max(1, (1 << 27) // n)
     if force:
         os.environ["FFTW_AMD_FORCE_LENS"] = force
     else:

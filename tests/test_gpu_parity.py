@@ -201,6 +201,33 @@ def test_register_kernels_wide_batches(torch_dev, n):
     assert aerror(y, oracle_dft(x, (n,), 9).reshape(9, n)) < TOL
 
 
+@pytest.mark.parametrize("k,lens", [(22, [128, 128, 256]), (23, [128, 128, 512]), (24, [128, 128, 1024]),
+                                    (25, [512, 128, 512])])
+def test_three_pass_powers_of_two(torch_dev, k, lens):
+    """2^22 ... 2^25: the three-pass split comes from the planner's per-position cost table
+    (pow2_three_pass_split); forward c2c against the oracle, and r2c of twice the length"""
+    torch, dev = torch_dev
+    n = 1 << k
+    rng = np.random.default_rng(k)
+    b = 2 if k <= 23 else 1
+    x = crand(rng, b, n)
+    dx = torch.from_numpy(x).to(dev)
+    dy = torch.zeros_like(dx)
+    p = fa.plan_many_dft(1, [n], b, dx, None, 1, n, dy, None, 1, n, fa.FORWARD)
+    assert [s.L for s in p.steps()] == lens, p.sprint()
+    p.execute()
+    p.sync()
+    assert aerror(dy.cpu().numpy(), oracle_dft(x, (n,), b).reshape(b, n)) < TOL
+    if k <= 23:
+        xr = rrand(rng, 2 * n)
+        dr = torch.from_numpy(xr).to(dev)
+        dc = torch.zeros(n + 1, dtype=torch.complex128, device=dev)
+        q = fa.plan_dft_r2c_1d(2 * n, dr, dc)
+        q.execute()
+        q.sync()
+        assert aerror(dc.cpu().numpy(), oracle_r2c(xr, (2 * n,))) < TOL
+
+
 def test_layouts_inplace_embed_split_guru_newarray(torch_dev):
     torch, dev = torch_dev
     rng = np.random.default_rng(9)
