@@ -228,6 +228,33 @@ def test_three_pass_powers_of_two(torch_dev, k, lens):
         assert aerror(dc.cpu().numpy(), oracle_r2c(xr, (2 * n,))) < TOL
 
 
+@pytest.mark.parametrize("k", [26, 28])
+def test_huge_single_transform_known_answer(torch_dev, k):
+    """one transform of 2^26 / 2^28 points (1 / 4 GiB): too long for the oracle, so the check is the
+    shifted-impulse known answer X[k] = exp(-2 pi i j0 k / n), evaluated on the device with the
+    index product reduced exactly in int64 (the reference's impulse test, verify-lib.c:285-340)"""
+    import math
+    torch, dev = torch_dev
+    n = 1 << k
+    j0 = 123456789 % n
+    x = torch.zeros(n, dtype=torch.complex128, device=dev)
+    x[j0] = 1.0
+    y = torch.zeros_like(x)
+    p = fa.plan_dft_1d(n, x, y, fa.FORWARD)
+    assert len(p.steps()) == 3, p.sprint()
+    p.execute()
+    p.sync()
+    worst = 0.0
+    step = 1 << 24
+    for s in range(0, n, step):
+        kk = torch.arange(s, min(n, s + step), dtype=torch.int64, device=dev)
+        ang = ((kk * j0) % n).to(torch.float64) * (-2.0 * math.pi / n)
+        worst = max(worst, (y[s:s + step] - torch.complex(torch.cos(ang), torch.sin(ang))).abs().max().item())
+    assert worst < 1e-13, worst
+    del p, x, y
+    torch.cuda.empty_cache()
+
+
 def test_layouts_inplace_embed_split_guru_newarray(torch_dev):
     torch, dev = torch_dev
     rng = np.random.default_rng(9)
