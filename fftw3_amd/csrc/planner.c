@@ -767,7 +767,7 @@ static int has_register_kernel(i64 L) {
 static void pow2_three_pass_split(i64 n, i64 *lens) {
     /*                              2^4   2^5   2^6   2^7   2^8   2^9   2^10 */
     static const double c_first[] = { 1.00, 1.00, 0.95, 0.80, 1.02, 0.87, 1.30 };
-    static const double c_mid[]   = { 0.77, 0.78, 0.75, 0.76, 0.99, 1.05, 1.20 };
+    static const double c_mid[]   = { 0.77, 0.78, 0.75, 0.76, 0.99, 0.90, 1.02 };
     static const double c_last[]  = { 0.95, 0.95, 0.90, 0.80, 0.80, 0.82, 0.84 };
     int e = 0, a, m, c, ba = 0, bm = 0, bc = 0;
     double best = 1e30;
