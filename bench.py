@@ -189,6 +189,69 @@ def run_slab(args, torch, fa, dist, world, rank, dev):
         dist.destroy_process_group()
 
 
+def spawn_ranks(nproc, argv, script=None, timeout=None):
+    """One fresh child process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its
+    environment (the contract of `python -m torch.distributed.run --nproc-per-node N`).
+    The batch split the ranks then apply is the block rule of fftw/mpi/block.c:35-42.
+    Rank 0's stdout (the one JSON line) is relayed; returns non-zero if any rank failed.
+    Children are started with subprocess (never an exec of this process) and killed as a
+    group of exact PIDs if one of them dies."""
+    import socket
+    import subprocess
+    script = script or os.path.abspath(__file__)
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(nproc):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    t_end = None if timeout is None else time.monotonic() + timeout
+    alive = set(range(nproc))
+    out0 = b""
+    try:
+        while alive:
+            for r in sorted(alive):
+                p = procs[r]
+                try:
+                    if r == 0:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or b""
+                    else:
+                        p.wait(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+                alive.discard(r)
+                if p.returncode != 0:
+                    rc = rc or p.returncode or 1
+                    sys.stderr.write("bench.py: rank %d exited with code %s\n" % (r, p.returncode))
+            if rc and alive or (t_end is not None and time.monotonic() > t_end):
+                rc = rc or 124
+                break
+    finally:
+        for r in alive:
+            procs[r].kill()
+        for r in alive:
+            try:
+                o, _ = procs[r].communicate(timeout=10)
+                if r == 0:
+                    out0 += o or b""
+            except Exception:
+                pass
+    # ONE JSON line on stdout; library chatter of rank 0 (e.g. "[Gloo] Rank 0 is connected ...") to stderr
+    for line in out0.decode(errors="replace").splitlines():
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +262,11 @@ def main():
     ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.
+        # It has not touched the GPU (no torch, no fftw3_amd yet) and never will.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import fftw3_amd as fa

@@ -33,8 +33,8 @@ typedef struct fftw_plan_s *fftw_plan;
 typedef struct fftw_iodim_s   { int n, is, os; }       fftw_iodim;
 typedef struct fftw_iodim64_s { ptrdiff_t n, is, os; } fftw_iodim64;
 
-/* r2r kinds exist so callers compile; the r2r family is outside the hot path
-    and its planners return NULL. */
+/* r2r kinds (reference fftw/fftw3.h:84-90); all eleven are planned and executed on the
+   GPU by fftw_plan_r2r_* / fftw_plan_many_r2r / fftw_plan_guru(64)_r2r. */
 typedef enum {
     FFTW_R2HC = 0, FFTW_HC2R = 1, FFTW_DHT = 2,
     FFTW_REDFT00 = 3, FFTW_REDFT01 = 4, FFTW_REDFT10 = 5, FFTW_REDFT11 = 6,

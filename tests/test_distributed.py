@@ -163,3 +163,59 @@ def test_two_rank_gloo_sharded_transform_and_gather(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out)
         assert "rank %d ok" % rank in out
+
+
+LAUNCH_WORKER = r'''
+import json, os, sys
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert sys.argv[1:] == ["--gpus", str(world), "--steps", "2"], sys.argv
+t = torch.tensor([float(rank)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+if os.environ.get("FAIL_RANK") == str(rank):
+    sys.exit(3)
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "max_rank": t.item(), "local_rank": os.environ["LOCAL_RANK"]}))
+else:
+    print("noise from rank", rank)          # must not reach the launcher's stdout
+dist.destroy_process_group()
+'''
+
+
+def test_bench_launcher_spawns_ranks_and_relays_rank0(tmp_path, capsys, monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE must start its own N ranks
+    (the driver's command form), relay rank 0's single line and fail if a rank fails."""
+    import json
+    import bench
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    script = tmp_path / "w.py"
+    script.write_text(LAUNCH_WORKER)
+    rc = bench.spawn_ranks(2, ["--gpus", "2", "--steps", "2"], script=str(script), timeout=240)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1, out
+    line = json.loads(out[0])
+    assert line == {"n_gpus": 2, "max_rank": 1.0, "local_rank": "0"}
+    monkeypatch.setenv("FAIL_RANK", "1")
+    rc = bench.spawn_ranks(2, ["--gpus", "2", "--steps", "2"], script=str(script), timeout=240)
+    assert rc != 0
+
+
+def test_bench_main_takes_the_launcher_branch_before_touching_torch(monkeypatch):
+    """--gpus 2 and no WORLD_SIZE: main() must hand over to spawn_ranks before importing
+    torch.cuda / fftw3_amd (a process that touched the GPU must not fork ranks)."""
+    import bench
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    seen = {}
+
+    def fake(n, argv, **kw):
+        seen["n"], seen["argv"] = n, list(argv)
+        return 0
+    monkeypatch.setattr(bench, "spawn_ranks", fake)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert seen == {"n": 2, "argv": ["--gpus", "2", "--steps", "1", "--warmup", "0"]}

@@ -1,5 +1,5 @@
 import sys, os, time, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import fftw3_amd as fa
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """fused two-pass kernel: correctness vs the two-launch path and the oracle, then timing"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import fftw3_amd as fa

@@ -1,7 +1,7 @@
 """exploration (not a test): single huge power-of-two transforms checked by the shifted-impulse
 known answer X[k] = exp(-2 pi i j0 k / n), evaluated on the device with exact index reduction"""
 import sys, os, time, math
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import fftw3_amd as fa
 for k in (26, 27, 28, 29):

@@ -1,6 +1,6 @@
 """exploration (not a test): create / execute / destroy many plans and watch free device memory"""
 import sys, os, gc
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import fftw3_amd as fa
 rng = np.random.default_rng(0)

@@ -1,6 +1,6 @@
 """exploration (not a test): per-step times of 1-D power-of-two sizes around 2^18"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import fftw3_amd as fa
 import ast

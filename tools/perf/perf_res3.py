@@ -1,6 +1,6 @@
 """perf exploration: do Infinity-Cache hits and HBM misses add up? two load-only plans on two streams"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import fftw3_amd as fa
 dev = torch.device("cuda:0")

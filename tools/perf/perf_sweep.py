@@ -1,7 +1,7 @@
 """exploration (not a test): the benchFFT-style sweep of power-of-two and cubic c2c sizes;
 prints ms per 4 GiB of data moved algorithmically (in + out) and the plan"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import time, torch
 import fftw3_amd as fa
 

@@ -1,6 +1,6 @@
 """one execution of the headline plan at reduced batch, for rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import fftw3_amd as fa
 dev = torch.device("cuda:0")
