@@ -128,6 +128,12 @@ _sig("fftw_plan_guru64_dft_r2c", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.PO
      _vp, _vp, C.c_uint)
 _sig("fftw_plan_guru64_dft_c2r", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.POINTER(iodim64),
      _vp, _vp, C.c_uint)
+_sig("fftw_plan_guru64_split_dft_r2c", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.POINTER(iodim64),
+     _vp, _vp, _vp, C.c_uint)
+_sig("fftw_plan_guru64_split_dft_c2r", _vp, C.c_int, C.POINTER(iodim64), C.c_int, C.POINTER(iodim64),
+     _vp, _vp, _vp, C.c_uint)
+_sig("fftw_execute_split_dft_r2c", None, _vp, _vp, _vp, _vp)
+_sig("fftw_execute_split_dft_c2r", None, _vp, _vp, _vp, _vp)
 _sig("fftw_execute_r2r", None, _vp, _vp, _vp)
 _sig("fftw_plan_r2r", _vp, C.c_int, _ip, _vp, _vp, _ip, C.c_uint)
 _sig("fftw_plan_r2r_1d", _vp, C.c_int, _vp, _vp, C.c_int, C.c_uint)
@@ -231,6 +237,14 @@ class Plan(object):
     def execute_split_dft(self, ri, ii, ro, io):
         self._need_device()
         lib.fftw_execute_split_dft(self.handle, ptr(ri), ptr(ii), ptr(ro), ptr(io))
+
+    def execute_split_dft_r2c(self, i, ro, io):
+        self._need_device()
+        lib.fftw_execute_split_dft_r2c(self.handle, ptr(i), ptr(ro), ptr(io))
+
+    def execute_split_dft_c2r(self, ri, ii, o):
+        self._need_device()
+        lib.fftw_execute_split_dft_c2r(self.handle, ptr(ri), ptr(ii), ptr(o))
 
     def execute_dft_r2c(self, i, o):
         self._need_device()
@@ -430,6 +444,19 @@ def plan_guru64_split_dft(dims, howmany_dims, ri, ii, ro, io, flags=ESTIMATE):
     return Plan(lib.fftw_plan_guru64_split_dft(len(dims), _iodims(dims), len(howmany_dims),
                                                _iodims(howmany_dims), ptr(ri), ptr(ii), ptr(ro),
                                                ptr(io), flags), (ri, ii, ro, io))
+
+
+def plan_guru64_split_dft_r2c(dims, howmany_dims, i, ro, io, flags=ESTIMATE):
+    """dims strides: `is` in reals, `os` in reals of the split output planes"""
+    return Plan(lib.fftw_plan_guru64_split_dft_r2c(len(dims), _iodims(dims), len(howmany_dims),
+                                                   _iodims(howmany_dims), ptr(i), ptr(ro), ptr(io),
+                                                   flags), (i, ro, io))
+
+
+def plan_guru64_split_dft_c2r(dims, howmany_dims, ri, ii, o, flags=ESTIMATE):
+    return Plan(lib.fftw_plan_guru64_split_dft_c2r(len(dims), _iodims(dims), len(howmany_dims),
+                                                   _iodims(howmany_dims), ptr(ri), ptr(ii), ptr(o),
+                                                   flags), (ri, ii, o))
 
 
 def plan_guru64_dft_r2c(dims, howmany_dims, i, o, flags=ESTIMATE):

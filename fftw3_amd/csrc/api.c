@@ -6,6 +6,7 @@
  * reported the FFTW way: planners return NULL, internal failures abort().
  */
 #include <pthread.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,28 +30,45 @@ const char fftw_codelet_optim[] = "";
    times the candidates on the device (overwriting the arrays, as FFTW_MEASURE
    does in the reference: A.c:18604) and records the winner as wisdom, which the
    wisdom export / import calls move between processes as text. */
+/* room for 2 * FA_MAXRANK dims of three 20-digit numbers each, plus the fixed fields */
+#define FA_WIS_KEY_CAP 1280
 typedef struct wis_s {
     struct wis_s *next;
-    char key[320];
+    char key[FA_WIS_KEY_CAP];
     fa_cfg cfg;
     double ms;
 } wis_entry;
 static wis_entry *g_wisdom = NULL;
 
+/* bounded append: never writes past key[cap - 1], however long the text would have been
+   (snprintf returns the would-be length, which must not be trusted as the new end) */
+static void kapp(char *key, size_t cap, size_t *len, const char *fmt, ...) {
+    va_list ap;
+    int n;
+    if (*len + 1 >= cap) return;
+    va_start(ap, fmt);
+    n = vsnprintf(key + *len, cap - *len, fmt, ap);
+    va_end(ap);
+    if (n < 0) return;
+    *len += (size_t)n;
+    if (*len > cap - 1) *len = cap - 1;
+}
+
 static void wis_key(const plan *p, char *key, size_t cap) {
     size_t len = 0;
     int i;
-    len += (size_t)snprintf(key + len, cap - len, "t%d s%d r%d", p->type, p->sign, p->rank);
-    for (i = 0; i < p->rank && len < cap; ++i)
-        len += (size_t)snprintf(key + len, cap - len, " %lld:%lld:%lld", p->dims[i].n, p->dims[i].is, p->dims[i].os);
+    key[0] = 0;
+    kapp(key, cap, &len, "t%d s%d r%d", p->type, p->sign, p->rank);
+    for (i = 0; i < p->rank; ++i)
+        kapp(key, cap, &len, " %lld:%lld:%lld", p->dims[i].n, p->dims[i].is, p->dims[i].os);
     if (p->type == FA_R2R) {
-        len += (size_t)snprintf(key + len, cap - len, " k");
-        for (i = 0; i < p->rank && len < cap; ++i) len += (size_t)snprintf(key + len, cap - len, "%d.", p->kinds[i]);
+        kapp(key, cap, &len, " k");
+        for (i = 0; i < p->rank; ++i) kapp(key, cap, &len, "%d.", p->kinds[i]);
     }
-    len += (size_t)snprintf(key + len, cap - len, " h%d", p->hrank);
-    for (i = 0; i < p->hrank && len < cap; ++i)
-        len += (size_t)snprintf(key + len, cap - len, " %lld:%lld:%lld", p->hdims[i].n, p->hdims[i].is, p->hdims[i].os);
-    snprintf(key + len, cap > len ? cap - len : 0, " i%lld o%lld p%d", p->in_im, p->out_im, p->inplace);
+    kapp(key, cap, &len, " h%d", p->hrank);
+    for (i = 0; i < p->hrank; ++i)
+        kapp(key, cap, &len, " %lld:%lld:%lld", p->hdims[i].n, p->hdims[i].is, p->hdims[i].os);
+    kapp(key, cap, &len, " i%lld o%lld p%d", p->in_im, p->out_im, p->inplace);
 }
 
 static wis_entry *wis_find(const char *key) {
@@ -135,7 +153,7 @@ static plan *finish_locked(plan *p, double *ri, double *ii, double *ro, double *
     for (i = 0; i < p->hrank; ++i) cnt *= p->hdims[i].n;
     p->out_written = FA_REAL_OUT(p->type) ? cnt : 2 * cnt;
     {
-        char key[320];
+        char key[FA_WIS_KEY_CAP];
         wis_entry *w;
         wis_key(p, key, sizeof(key));
         w = wis_find(key);
@@ -709,7 +727,7 @@ int fftw_import_wisdom_from_string(const char *input) {
     if (!input || strncmp(input, "(fftw3_amd_wisdom-1", 19)) return 0;
     c = input + 19;
     for (;;) {
-        char key[320];
+        char key[FA_WIS_KEY_CAP];
         size_t chunk;
         int pipe, lmax, small, n = 0;
         double ms;

@@ -55,6 +55,34 @@ FA_DEV void store_elem(double *p, i64 a, i64 im, int flags, cplx v) {
     }
 }
 
+/* 16-byte complex access with an optional nontemporal hint (global_load/store_dwordx4 ... nt).
+   The planner asks for it on the streams that touch the caller's arrays once (input of the
+   first pass, output of the last), so that the Infinity Cache keeps the scratch image between
+   two passes instead (tests/micro/membw3.hip: 12.5 -> 10.0 us per 2^20-point transform). */
+typedef double fa_d2 __attribute__((ext_vector_type(2)));
+template <bool NT> FA_DEV cplx ld_cplx(const double *p) {
+    if (NT) {
+        fa_d2 v = __builtin_nontemporal_load(reinterpret_cast<const fa_d2 *>(p));
+        return c_make(v.x, v.y);
+    }
+    return *reinterpret_cast<const cplx *>(p);
+}
+template <bool NT> FA_DEV void st_cplx(double *p, cplx v) {
+    if (NT) {
+        fa_d2 w = { v.x, v.y };
+        __builtin_nontemporal_store(w, reinterpret_cast<fa_d2 *>(p));
+    } else {
+        *reinterpret_cast<cplx *>(p) = v;
+    }
+}
+
+/* linear block id -> work id such that XCD x (= block % 8) walks the contiguous range
+   [x * n/8, (x+1) * n/8) in launch order; identity when n is not a multiple of 8 */
+FA_DEV i64 fa_xcd_remap(i64 blk, i64 n) {
+    if (n & 7) return blk;
+    return (blk & 7) * (n >> 3) + (blk >> 3);
+}
+
 /* w^m from the two-level table: (cos, sin)(2 pi m / n) */
 FA_DEV cplx tw2(const cplx *lo, const cplx *hi, int shift, i64 m) {
     cplx a = lo[m & ((1LL << shift) - 1)];

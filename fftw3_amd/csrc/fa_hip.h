@@ -43,21 +43,6 @@ int fa_hip_launch_step(const fftw_amd_step_desc *desc, double *const *bufs,
                        void *const *tables, long long chunk_start, long long chunk_n,
                        void *stream);
 
-/* Both passes of batched N = 1024 x 1024 transforms in one persistent launch
-   (fused1024.hpp).  ctrl: device ints [2*batch + 4]: done1[batch], done2[batch],
-   ticket (8 bytes), error.  Zeroed here on the stream before the launch. */
-int fa_hip_launch_fused1024(const double *in, double *out, double *scratch, int nslots, int lag,
-                            long long in_bs, long long out_bs, long long batch, int flags,
-                            const void *w1024, const void *tw_lo, const void *tw_hi, int tw_shift,
-                            int *ctrl, void *stream);
-
-/* One launch of the sync-free two-pass pipeline (mixed1024.hpp): pass 1 of n1
-   transforms starting at `in` into slot_w, pass 2 of n2 transforms from slot_r to `out`. */
-int fa_hip_launch_mixed1024(const double *in, double *out, double *slot_w, const double *slot_r,
-                            long long in_bs, long long out_bs, int n1, int n2, int flags,
-                            const void *w1024, const void *tw_lo, const void *tw_hi, int tw_shift,
-                            void *stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -124,13 +124,6 @@ struct fftw_plan_s {
     void *ev_a[4], *ev_b[4], *ev_begin, *ev_end[2];
     int failed;
 
-    /* fused two-pass launch for batched n = 2^20 (fused1024.hpp) */
-    int fused, fused_slots, fused_lag;
-    int mixed, mixed_chunk;     /* sync-free pass pipeline (mixed1024.hpp): transforms per launch */
-    double *fused_scratch;
-    int *fused_ctrl;            /* device: done1[batch], done2[batch], ticket, error */
-    int *fused_err_host;        /* pinned copy of the error word of the last launch */
-
     /* staging for plain host pointers */
     double *stage_in, *stage_out;
     size_t stage_in_bytes, stage_out_bytes;

@@ -17,9 +17,6 @@
 #include "common.hpp"
 
 #include "pass1024.hpp"
-#include "stream1024.hpp"
-#include "fused1024.hpp"
-#include "mixed1024.hpp"
 
 /* ------------------------------------------------------------------------ */
 /* generic LDS pass kernel (runtime radices)                                 */
@@ -928,6 +925,7 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
     pa.ndims = d->ndims;
     pa.flags = d->flags;
     pa.lo_sh = 0; pa.lo_is = d->tile_lo_is; pa.lo_os = d->tile_lo_os;
+    pa.dbg = NULL;
     if (d->tile_lo_n > 1) {
         if (d->tile_lo_n != 2 && d->tile_lo_n != 4) return 1;
         pa.lo_sh = d->tile_lo_n == 2 ? 1 : 2;
@@ -942,40 +940,6 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
     bool in_t = pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l);
     bool out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);
     int tw = d->tw_n == 0 ? 0 : ((d->flags & FFTW_AMD_F_TW_IN) ? 2 : 1);
-    {
-        /* long tile lists: the persistent software-pipelined form (one workgroup per CU) */
-        static int stream_mode = -1, ncu = 0;
-        if (stream_mode < 0) {
-            const char *e = getenv("FFTW_AMD_STREAM");
-            hipDeviceProp_t prop;
-            int dev = 0;
-            stream_mode = e ? atoi(e) : 0;   /* opt-in: measured slower than the 2-workgroup form */
-            FA_CHECK(hipGetDevice(&dev));
-            FA_CHECK(hipGetDeviceProperties(&prop, dev));
-            ncu = prop.multiProcessorCount;
-        }
-        if (stream_mode && nblocks >= 4 * (i64)ncu && pa.lo_sh == 0) {
-            S1024Args sa;
-            for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
-                sa.ps.dn[i] = pa.dn[i]; sa.ps.dis[i] = pa.dis[i]; sa.ps.dos[i] = pa.dos[i]; sa.ps.dtw[i] = pa.dtw[i];
-            }
-            sa.ps.src = pa.src; sa.ps.dst = pa.dst; sa.ps.is_l = pa.is_l; sa.ps.os_l = pa.os_l;
-            sa.ps.ntiles0 = pa.ntiles; sa.ps.total = nblocks; sa.ps.ndims = pa.ndims; sa.ps.flags = pa.flags;
-            sa.w1024 = pa.w1024; sa.tw_lo = pa.tw_lo; sa.tw_hi = pa.tw_hi; sa.tw_shift = pa.tw_shift;
-            dim3 sgrid((unsigned)ncu, 1, 1);
-            const size_t lds = FA_S1024_LDS_CPLX * sizeof(cplx);
-#define FA_S1024_CASE(I, O, W) if (in_t == I && out_t == O && tw == W) { \
-                static bool done = false; \
-                if (!done) { FA_CHECK(hipFuncSetAttribute((const void *)stream1024_kernel<I, O, W>, \
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; } \
-                hipLaunchKernelGGL((stream1024_kernel<I, O, W>), sgrid, dim3(256), lds, st, sa); return 0; }
-            FA_S1024_CASE(true, true, 0)  FA_S1024_CASE(true, true, 1)  FA_S1024_CASE(true, true, 2)
-            FA_S1024_CASE(false, true, 0) FA_S1024_CASE(false, true, 1) FA_S1024_CASE(false, true, 2)
-            FA_S1024_CASE(true, false, 0) FA_S1024_CASE(true, false, 1) FA_S1024_CASE(true, false, 2)
-            FA_S1024_CASE(false, false, 0) FA_S1024_CASE(false, false, 1) FA_S1024_CASE(false, false, 2)
-#undef FA_S1024_CASE
-        }
-    }
 #define FA_P1024_CASE(I, O, W) if (in_t == I && out_t == O && tw == W) { launch_p1024_variant<I, O, W>(pa, grid, st); return 0; }
     FA_P1024_CASE(true, true, 0)  FA_P1024_CASE(true, true, 1)  FA_P1024_CASE(true, true, 2)
     FA_P1024_CASE(false, true, 0) FA_P1024_CASE(false, true, 1) FA_P1024_CASE(false, true, 2)
@@ -1178,10 +1142,27 @@ static i64 r2r_len_of(int mode, i64 N) {
     return N;
 }
 
+static int launch_step_kind(const fftw_amd_step_desc *d, double *const *bufs,
+                            void *const *tables, long long cs, long long cn, hipStream_t st);
+
+/* A launch that the runtime refuses (bad grid / LDS configuration, missing code object) leaves
+   no trace unless hipGetLastError is asked: without this check the step would "succeed" and the
+   output would silently keep its old contents. */
 extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bufs,
                                   void *const *tables, long long cs, long long cn,
                                   void *stream) {
-    hipStream_t st = (hipStream_t)stream;
+    int r = launch_step_kind(d, bufs, tables, cs, cn, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fprintf(stderr, "fftw3_amd: kernel launch of step kind %d (L=%d, variant %d) failed: %s\n",
+                d->kind, d->L, d->variant, hipGetErrorString(e));
+        return -1;
+    }
+    return r;
+}
+
+static int launch_step_kind(const fftw_amd_step_desc *d, double *const *bufs,
+                            void *const *tables, long long cs, long long cn, hipStream_t st) {
     switch (d->kind) {
     case FFTW_AMD_STEP_PASS:
         return launch_pass(d, bufs, tables, cs, cn, st);
@@ -1320,63 +1301,4 @@ extern "C" int fa_hip_launch_step(const fftw_amd_step_desc *d, double *const *bu
         fprintf(stderr, "fftw3_amd: unknown step kind %d\n", d->kind);
         return -1;
     }
-}
-
-extern "C" int fa_hip_launch_fused1024(const double *in, double *out, double *scratch, int nslots, int lag,
-                                       long long in_bs, long long out_bs, long long batch, int flags,
-                                       const void *w1024, const void *tw_lo, const void *tw_hi, int tw_shift,
-                                       int *ctrl, void *stream) {
-    static int ncu = 0;
-    static bool attr_done = false;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t lds = FA_P1024_LDS_DOUBLES * sizeof(double);
-    if (((uintptr_t)in % 16) || ((uintptr_t)out % 16) || (in_bs % 2) || (out_bs % 2)) return 1;
-    if (!ncu) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        FA_CHECK(hipGetDevice(&dev));
-        FA_CHECK(hipGetDeviceProperties(&prop, dev));
-        ncu = prop.multiProcessorCount;
-    }
-    if (!attr_done) {
-        FA_CHECK(hipFuncSetAttribute((const void *)fused1024_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    Fused1024Args a;
-    a.in = in; a.out = out; a.scratch = scratch;
-    a.in_bs = in_bs; a.out_bs = out_bs; a.batch = batch;
-    a.nslots = nslots; a.lag = lag; a.nunits = batch + lag;
-    a.done1 = ctrl; a.done2 = ctrl + batch;
-    /* the 8-byte ticket stays aligned: ctrl is 16-byte aligned and 2*batch ints are a multiple of 8 bytes */
-    a.ticket = (unsigned long long *)(ctrl + 2 * batch);
-    a.error = ctrl + 2 * batch + 2;
-    a.w1024 = (const cplx *)w1024; a.tw_lo = (const cplx *)tw_lo; a.tw_hi = (const cplx *)tw_hi;
-    a.tw_shift = tw_shift; a.flags = flags;
-    { const char *e = getenv("FFTW_AMD_FUSED_DBG"); if (e) a.flags |= atoi(e) << 24; }
-    FA_CHECK(hipMemsetAsync(ctrl, 0, sizeof(int) * (size_t)(2 * batch + 16), st));
-    hipLaunchKernelGGL(fused1024_kernel, dim3(2 * ncu), dim3(256), lds, st, a);
-    return 0;
-}
-
-extern "C" int fa_hip_launch_mixed1024(const double *in, double *out, double *slot_w, const double *slot_r,
-                                       long long in_bs, long long out_bs, int n1, int n2, int flags,
-                                       const void *w1024, const void *tw_lo, const void *tw_hi, int tw_shift,
-                                       void *stream) {
-    static bool attr_done = false;
-    const size_t lds = FA_P1024_LDS_DOUBLES * sizeof(double);
-    if (!attr_done) {
-        FA_CHECK(hipFuncSetAttribute((const void *)mixed1024_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    Mixed1024Args a;
-    a.in = in; a.out = out; a.slot_w = slot_w; a.slot_r = slot_r;
-    a.in_bs = in_bs; a.out_bs = out_bs; a.n1 = n1; a.n2 = n2;
-    a.w1024 = (const cplx *)w1024; a.tw_lo = (const cplx *)tw_lo; a.tw_hi = (const cplx *)tw_hi;
-    a.tw_shift = tw_shift; a.flags = flags;
-    int blocks = (n1 + n2) * 128;
-    if (blocks <= 0) return 0;
-    hipLaunchKernelGGL(mixed1024_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
-    return 0;
 }

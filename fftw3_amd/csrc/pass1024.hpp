@@ -142,6 +142,7 @@ struct P1024Tile {
     /* two-level tile dim: sequence t = (t & lo_mask) + (t >> lo_sh) << lo_sh */
     int lo_sh;
     i64 lo_is, lo_os;
+    long long *dbg;       /* ABL & 8 only: per-workgroup time stamps */
 };
 
 /* offset of sequence t of a tile on the source / destination side */
@@ -150,63 +151,79 @@ struct P1024Tile {
 
 /* HAS_TW: 0 none, 1 inter-pass twiddle on the output, 2 on the input.
    `plane` is FA_P1024_LDS_DOUBLES doubles of LDS.  All 256 work-items call. */
-typedef unsigned int fa_u32x4 __attribute__((ext_vector_type(4)));
-
-/* ST_SC1: the tile is handed to another workgroup inside the launch, so its
-   stores are write-through (sc1) buffer stores (guide section 6 G16, form R1) */
-/* hooks let a persistent caller slip independent scalar work (next ticket,
-   dependency poll) under the tile's memory latency */
-struct P1024NoHook {
-    FA_DEV void after_loads() {}
-    FA_DEV void mid() {}
-};
-
-template <bool IN_T, bool OUT_T, int HAS_TW, bool ST_SC1, class Hook>
-FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid, Hook &hook) {
+/* ABL (tests/micro/p1024_ablate.hip only; 0 in the product): timing ablations that leave
+   the memory footprint alone -- 1 no butterflies, 2 no twiddles, 4 no LDS exchange */
+template <bool IN_T, bool OUT_T, int HAS_TW, int ABL = 0>
+FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid) {
     /* ---- load: item (ai, ti) owns l = ai + 32 i */
     const int ti = IN_T ? (tid & 7) : (tid >> 5);
     const int ai = IN_T ? (tid >> 3) : (tid & 31);
+    const int to = OUT_T ? (tid & 7) : (tid >> 5);
+    const int dq = OUT_T ? (tid >> 3) : (tid & 31);
+
+    /* ---- every table value this item will need is requested BEFORE the tile's data: the
+       vector-memory pipe returns loads in order, so a table load issued after the data has
+       been consumed pays a whole round trip through queues that the other workgroups keep
+       full (measured with time stamps, tests/micro/p1024_ablate.hip: 4.4 us per tile in
+       pass 2, 1 us in pass 1 -- the workgroup life, and with it the pass, is that much longer) */
+    cplx pw1024[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) pw1024[s] = (ABL & 2) ? c_make(1.0, 0.0) : a.w1024[ai << s];
+    cplx twl[6], twh[6];
+    if (HAS_TW != 0 && !(ABL & 2)) {
+        const i64 q = a.q0 + (i64)((HAS_TW == 2 ? ti : to) >> a.lo_sh) * a.dtw0;
+        const i64 mask = (1LL << a.tw_shift) - 1;
+        const i64 m0 = q * (HAS_TW == 2 ? ai : dq);
+        twl[5] = a.tw_lo[m0 & mask]; twh[5] = a.tw_hi[m0 >> a.tw_shift];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const i64 m = (q * 32) << s;
+            twl[s] = a.tw_lo[m & mask]; twh[s] = a.tw_hi[m >> a.tw_shift];
+        }
+    }
     cplx x[32];
     {
         const double *p = a.src + (i64)ai * a.is_l + FA_TILE_SOFF(a, ti);
         const i64 step = 32 * a.is_l;
-        if ((ti >> a.lo_sh) < a.Tcur) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) x[i] = *reinterpret_cast<const cplx *>(p + i * step);
-        } else {
+        if ((ti >> a.lo_sh) >= a.Tcur) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) x[i] = c_make(0.0, 0.0);
+        } else if (a.flags & FFTW_AMD_F_NT_IN) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) x[i] = ld_cplx<true>(p + i * step);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) x[i] = ld_cplx<false>(p + i * step);
         }
-        hook.after_loads();
         if (a.flags & FFTW_AMD_F_SWAP_IN) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) { double s = x[i].x; x[i].x = x[i].y; x[i].y = s; }
         }
     }
+    if (ABL & 8) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) a.dbg[1] = wall_clock64();
+    }
 
     /* ---- inter-pass twiddle on the input: conj(w_N^((ai + 32 i) q)) */
-    if (HAS_TW == 2) {
-        const i64 q = a.q0 + (i64)(ti >> a.lo_sh) * a.dtw0;
-        cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * ai);
+    if (HAS_TW == 2 && !(ABL & 2)) {
+        cplx base = c_mul(twl[5], twh[5]);
         cplx pw[5];
 #pragma unroll
-        for (int s = 0; s < 5; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * 32) << s);
+        for (int s = 0; s < 5; ++s) pw[s] = c_mul(twl[s], twh[s]);
         TwTree<4, 0, true, false>::run(x, pw, base);
     }
 
     /* ---- first radix-32 butterfly over i, then w_1024^(a d) */
-    bfly32(x);
-    {
-        cplx pw[5];
-#pragma unroll
-        for (int s = 0; s < 5; ++s) pw[s] = a.w1024[ai << s];
-        TwTree<4, 0, false, true>::run(x, pw, c_make(1.0, 0.0));
-    }
+    if (!(ABL & 1)) bfly32(x);
+    if (!(ABL & 2)) TwTree<4, 0, false, true>::run(x, pw1024, c_make(1.0, 0.0));
 
     /* ---- exchange through LDS, one real plane at a time */
-    const int to = OUT_T ? (tid & 7) : (tid >> 5);
-    const int dq = OUT_T ? (tid >> 3) : (tid & 31);
     cplx y[32];
+    if (ABL & 4) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) y[q] = x[slot32(q)];
+    } else {
 #pragma unroll
     for (int d = 0; d < 32; ++d) plane[lds_index<IN_T, OUT_T>(d, ai, ti)] = x[slot32(d)].x;
     __syncthreads();
@@ -218,54 +235,48 @@ FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid, Hook &h
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 32; ++q) y[q].y = plane[lds_index<IN_T, OUT_T>(dq, q, to)];
-
-    hook.mid();
+    }
 
     /* ---- second radix-32 butterfly over a: X[dq + 32 c] in y[slot32(c)] */
-    bfly32(y);
+    if (!(ABL & 1)) bfly32(y);
 
     /* ---- inter-pass twiddle conj(w_N^((dq + 32 c) q)), q = position of this sequence */
-    if (HAS_TW == 1) {
-        const i64 q = a.q0 + (i64)(to >> a.lo_sh) * a.dtw0;
-        cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * dq);
+    if (HAS_TW == 1 && !(ABL & 2)) {
+        cplx base = c_mul(twl[5], twh[5]);
         cplx pw[5];
 #pragma unroll
-        for (int s = 0; s < 5; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * 32) << s);
+        for (int s = 0; s < 5; ++s) pw[s] = c_mul(twl[s], twh[s]);
         TwTree<4, 0, true, true>::run(y, pw, base);
     }
 
     /* ---- store */
-    if (ST_SC1) {
-        /* wave-uniform descriptor over the tile's destination; per-lane byte offsets */
-        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, 0x7fffffff, 0x00020000);
-        const int off0 = (int)(((i64)dq * a.os_l + FA_TILE_DOFF(a, to)) * 8);
-        const int step = (int)(32 * a.os_l * 8);
-        if ((to >> a.lo_sh) < a.Tcur) {
-#pragma unroll
-            for (int c = 0; c < 32; ++c) {
-                cplx v = y[slot32(c)];
-                fa_u32x4 w;
-                __builtin_memcpy(&w, &v, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, off0 + c * step, 0, 16);
-            }
-        }
-    } else if ((to >> a.lo_sh) < a.Tcur) {
+    if ((ABL & 8) && tid == 0) a.dbg[2] = wall_clock64();
+    if ((to >> a.lo_sh) < a.Tcur) {
         double *p = a.dst + (i64)dq * a.os_l + FA_TILE_DOFF(a, to);
         const i64 step = 32 * a.os_l;
         const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
+        if (a.flags & FFTW_AMD_F_NT_OUT) {
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            cplx v = y[slot32(c)];
-            if (sw) { double s = v.x; v.x = v.y; v.y = s; }
-            *reinterpret_cast<cplx *>(p + c * step) = v;
+            for (int c = 0; c < 32; ++c) {
+                cplx v = y[slot32(c)];
+                if (sw) { double s = v.x; v.x = v.y; v.y = s; }
+                st_cplx<true>(p + c * step, v);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                cplx v = y[slot32(c)];
+                if (sw) { double s = v.x; v.x = v.y; v.y = s; }
+                st_cplx<false>(p + c * step, v);
+            }
         }
     }
-}
-
-template <bool IN_T, bool OUT_T, int HAS_TW, bool ST_SC1 = false>
-FA_DEV void p1024_tile(const P1024Tile &a, double *plane, const int tid) {
-    P1024NoHook h;
-    p1024_tile<IN_T, OUT_T, HAS_TW, ST_SC1, P1024NoHook>(a, plane, tid, h);
+    if (ABL & 8) {
+        if (tid == 0) a.dbg[3] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) a.dbg[4] = wall_clock64();
+        if ((tid & 63) == 0) a.dbg[12 + (tid >> 6)] = wall_clock64();   /* every wave's own end */
+    }
 }
 
 struct P1024Args {
@@ -281,24 +292,35 @@ struct P1024Args {
     int ndims, flags;
     int lo_sh;
     i64 lo_is, lo_os;
+    long long *dbg;
 };
 
-template <bool IN_T, bool OUT_T, int HAS_TW>
+template <bool IN_T, bool OUT_T, int HAS_TW, int ABL = 0>
 __global__ void __launch_bounds__(256, 2)
 pass1024_kernel(const P1024Args a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
-    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
-    i64 tile = blk % a.ntiles;
-    i64 rest = blk / a.ntiles;
+    long long t_first = 0;
+    if (ABL & 8) t_first = wall_clock64();
+    /* workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8): give every XCD one
+       contiguous eighth of the tile list, so that the 128-byte segments its CUs touch at
+       the same time are neighbours in memory (tests/micro/membw2.hip: +3...15 %) */
+    /* the launcher keeps the grid below 2^31 blocks: 32-bit index arithmetic (a 64-bit
+       division is ~130 instructions on this ISA, and this prologue is on every workgroup's
+       critical path before its first load) */
+    unsigned blk = (unsigned)fa_xcd_remap((i64)blockIdx.x, (i64)gridDim.x);
+    const unsigned nt = (unsigned)a.ntiles;
+    unsigned tile = blk % nt;
+    unsigned rest = blk / nt;
     i64 soff = 0, doff = 0, twb = 0;
     for (int d = 1; d < a.ndims; ++d) {
-        i64 idx = rest % a.dn[d];
-        rest /= a.dn[d];
-        soff += idx * a.dis[d];
-        doff += idx * a.dos[d];
-        twb += idx * a.dtw[d];
+        const unsigned dn = (unsigned)a.dn[d];
+        unsigned idx = rest % dn;
+        rest /= dn;
+        soff += (i64)idx * a.dis[d];
+        doff += (i64)idx * a.dos[d];
+        twb += (i64)idx * a.dtw[d];
     }
-    const i64 t0 = tile * (8 >> a.lo_sh);
+    const i64 t0 = (i64)tile * (8 >> a.lo_sh);
     P1024Tile t;
     t.lo_sh = a.lo_sh; t.lo_is = a.lo_is; t.lo_os = a.lo_os;
     t.src = a.src + soff + t0 * a.dis[0];
@@ -309,7 +331,19 @@ pass1024_kernel(const P1024Args a) {
     t.w1024 = a.w1024; t.tw_lo = a.tw_lo; t.tw_hi = a.tw_hi; t.tw_shift = a.tw_shift;
     t.Tcur = (int)((a.dn[0] - t0 < (8 >> a.lo_sh)) ? (a.dn[0] - t0) : (8 >> a.lo_sh));
     t.flags = a.flags;
-    p1024_tile<IN_T, OUT_T, HAS_TW>(t, plane, threadIdx.x);
+    t.dbg = NULL;
+    if (ABL & 8) {
+        t.dbg = a.dbg + (i64)blockIdx.x * 16;
+        if (threadIdx.x == 0) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            t.dbg[0] = wall_clock64();
+            t.dbg[5] = hw; t.dbg[6] = xcc; t.dbg[7] = (long long)blk; t.dbg[8] = t_first;
+        }
+    }
+    p1024_tile<IN_T, OUT_T, HAS_TW, ABL>(t, plane, threadIdx.x);
 }
 
 #endif /* FA_PASS1024_HPP */

@@ -24,17 +24,18 @@
 
 typedef struct fftw_plan_s plan;
 
-static size_t g_chunk_bytes = (size_t)1 << 30;
+/* scratch per chunk: what one chunk writes between two passes must still be in the 256 MiB
+   Infinity Cache when the next pass reads it (membw3: 16 transforms of 2^20 best, 64 lose it) */
+#define FA_DEFAULT_CHUNK_BYTES ((size_t)256 << 20)
+static size_t g_chunk_bytes = FA_DEFAULT_CHUNK_BYTES;
 static i64 g_lmax_multi = 1024;
 static int g_pipeline = 0;   /* two-stream chunk pipeline: off under FFTW_ESTIMATE (each kernel then owns the machine and
                                   its launch duration is its roofline), a FFTW_MEASURE candidate, FFTW_AMD_PIPELINE=1 */
 static int g_small_tiles = 1;
 static int g_long_first = 0;
 static i64 g_tile_elems = 0;
-static int g_mixed = 0, g_mixed_chunk = 4;
-static int g_fused = 0, g_fused_lag = 5, g_fused_slots = 10;   /* opt-in: FFTW_AMD_FUSED=1 */
 
-void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : ((size_t)1 << 30); }
+void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : FA_DEFAULT_CHUNK_BYTES; }
 
 static i64 iabs(i64 v) { return v < 0 ? -v : v; }
 
@@ -58,16 +59,6 @@ plan *fa_plan_new(void) {
     p->in_im = p->out_im = 1;
     e = getenv("FFTW_AMD_CHUNK_BYTES");
     if (e && atoll(e) > 0) g_chunk_bytes = (size_t)atoll(e);
-    e = getenv("FFTW_AMD_FUSED");
-    if (e) g_fused = atoi(e);
-    e = getenv("FFTW_AMD_MIXED");
-    if (e) g_mixed = atoi(e);
-    e = getenv("FFTW_AMD_MIXED_CHUNK");
-    if (e && atoi(e) >= 1) g_mixed_chunk = atoi(e);
-    e = getenv("FFTW_AMD_FUSED_SLOTS");
-    if (e && atoi(e) >= 2) g_fused_slots = atoi(e);
-    e = getenv("FFTW_AMD_FUSED_LAG");
-    if (e && atoi(e) >= 1) g_fused_lag = atoi(e);
     e = getenv("FFTW_AMD_SMALL_TILES");
     if (e) g_small_tiles = atoi(e);
     e = getenv("FFTW_AMD_TILE_ELEMS");
@@ -107,9 +98,6 @@ void fa_plan_free(plan *p) {
         for (i = 2; i < p->nbufs; ++i) fa_hip_free(p->dbuf[i]);
         fa_hip_free(p->stage_in);
         fa_hip_free(p->stage_out);
-        fa_hip_free(p->fused_scratch);
-        fa_hip_free(p->fused_ctrl);
-        if (p->fused_err_host) fa_hip_host_free(p->fused_err_host);
         if (p->pstream[0]) {
             for (i = 0; i < 4; ++i) { fa_hip_event_destroy(p->ev_a[i]); fa_hip_event_destroy(p->ev_b[i]); }
             fa_hip_event_destroy(p->ev_begin);
@@ -1745,7 +1733,43 @@ static void build_steps(plan *p) {
     }
 }
 
+/* Cache policy of the streams that touch the caller's arrays (FFTW_AMD_F_NT_IN / NT_OUT).
+   An array that one execution reads once (or writes and never reads back) is moved with
+   nontemporal accesses when the batch is too large to stay cached anyway: the Infinity
+   Cache (256 MiB) then keeps the scratch image between two passes of a chunk instead of
+   input / output lines nobody asks for again (tests/micro/membw3.hip).  Small problems keep
+   plain accesses so that a consumer kernel still finds the output on chip. */
+static int g_nt_policy = -1;      /* FFTW_AMD_NT: 0 never, 1 by size (default), 2 always */
+static void mark_streaming_accesses(plan *p) {
+    int i, j;
+    double touched = ((double)(p->in_hi - p->in_lo) + (double)(p->out_hi - p->out_lo)) * sizeof(double);
+    if (g_nt_policy < 0) { const char *e = getenv("FFTW_AMD_NT"); g_nt_policy = e ? atoi(e) : 1; }
+    if (g_nt_policy == 0 || (g_nt_policy == 1 && touched < 384.0 * 1048576.0)) return;
+    for (i = 0; i < p->nsteps; ++i) {
+        fftw_amd_step_desc *s = &p->steps[i];
+        if (s->src_buf == 0) {
+            int readers = 0;
+            for (j = 0; j < p->nsteps; ++j) readers += (p->steps[j].src_buf == 0) || (p->inplace && p->steps[j].src_buf == 1);
+            if (readers == 1) s->flags |= FFTW_AMD_F_NT_IN;
+        }
+        if (s->dst_buf == 1) {
+            int later = 0;
+            for (j = i + 1; j < p->nsteps; ++j)
+                later += p->steps[j].src_buf == 1 || p->steps[j].aux_buf == 1 || (p->inplace && p->steps[j].src_buf == 0);
+            if (!later) s->flags |= FFTW_AMD_F_NT_OUT;
+        }
+    }
+}
+
+static int fa_build_steps_sized(plan *p);
+
 int fa_build(plan *p) {
+    int r = fa_build_steps_sized(p);
+    if (r == 0 && p->batch > 0) mark_streaming_accesses(p);
+    return r;
+}
+
+static int fa_build_steps_sized(plan *p) {
     i64 per_elem = 0;
     int i;
     p->batch = p->hrank ? p->hdims[0].n : 1;
@@ -1834,26 +1858,6 @@ int fa_device_init(plan *p) {
             fa_plan_free(q);
         }
     }
-    /* batched contiguous n = 2^20: both passes in one persistent launch */
-    if ((g_fused || g_mixed) && p->type == FA_C2C && p->rank == 1 && p->dims[0].n == ((i64)1 << 20) &&
-        p->dims[0].is == 2 && p->dims[0].os == 2 && p->hrank == 1 && p->nsteps == 2 &&
-        p->in_im == 1 && p->out_im == 1 && p->batch >= 8 && p->batch < ((i64)1 << 28) &&
-        p->steps[0].variant == FFTW_AMD_K_P1024 && p->steps[1].variant == FFTW_AMD_K_P1024 &&
-        (p->hdims[0].is % 2) == 0 && (p->hdims[0].os % 2) == 0) {
-        if (g_mixed) {
-            p->mixed = 1;
-            p->mixed_chunk = g_mixed_chunk;
-            if (p->mixed_chunk > p->batch) p->mixed_chunk = (int)p->batch;
-        }
-        p->fused = 1;
-        p->fused_lag = g_fused_lag;
-        p->fused_slots = g_fused_slots > g_fused_lag ? g_fused_slots : g_fused_lag + 3;
-        if (p->mixed && p->fused_slots < 2 * p->mixed_chunk) p->fused_slots = 2 * p->mixed_chunk;
-        p->fused_scratch = (double *)fa_hip_malloc((size_t)p->fused_slots * ((size_t)1 << 20) * 16);
-        p->fused_ctrl = (int *)fa_hip_malloc(sizeof(int) * (size_t)(2 * p->batch + 16));
-        p->fused_err_host = (int *)fa_hip_host_malloc(sizeof(int) * 4);
-        if (p->fused_err_host) p->fused_err_host[0] = 0;
-    }
     /* chunk pipeline: worth it when there are several chunks of >= 2 steps */
     p->nslots = 1;
     if (p->chunk > 0 && p->nsteps >= 2 && (p->batch + p->chunk - 1) / p->chunk >= 3 &&
@@ -1876,6 +1880,54 @@ int fa_device_init(plan *p) {
             p->dbuf[i] = (double *)fa_hip_malloc((size_t)p->buf_reals[i] * sizeof(double) * (size_t)p->nslots);
     p->dev_ready = 1;
     return 0;
+}
+
+/* How a host array is laid out in its device staging buffer.  Offsets count doubles relative to
+   the pointer of the "real" part; im is the caller's real -> imaginary distance. */
+typedef struct {
+    int two;        /* 1: two packed planes of `span` doubles each, 0: one span [lo, hi] covering both parts */
+    i64 lo, hi;     /* touched offsets (two: of each plane; one span: of both parts together) */
+    i64 span;
+    i64 im_dev;     /* real -> imaginary distance inside the staging buffer */
+} stage_layout;
+
+static stage_layout stage_layout_of(i64 lo, i64 hi, i64 im) {
+    stage_layout L;
+    L.span = hi - lo + 1;
+    L.two = im != 0 && iabs(im) >= L.span;
+    if (L.two) {
+        L.lo = lo; L.hi = hi;
+        L.im_dev = im > 0 ? L.span : -L.span;
+    } else {
+        L.lo = im < 0 ? lo + im : lo;
+        L.hi = im > 0 ? hi + im : hi;
+        L.span = L.hi - L.lo + 1;
+        L.im_dev = im;
+    }
+    return L;
+}
+static size_t stage_bytes(const stage_layout *L) { return (size_t)L->span * (L->two ? 2 : 1) * sizeof(double); }
+/* device address that plays the role of the caller's real-part pointer */
+static double *stage_origin(const stage_layout *L, double *st) {
+    return st - L->lo + ((L->two && L->im_dev < 0) ? L->span : 0);
+}
+static void stage_h2d(const stage_layout *L, double *st, const double *re, i64 im, void *stream) {
+    double *o = stage_origin(L, st);
+    if (L->two) {
+        fa_hip_memcpy_h2d(o + L->lo, re + L->lo, (size_t)L->span * sizeof(double), stream);
+        fa_hip_memcpy_h2d(o + L->im_dev + L->lo, re + im + L->lo, (size_t)L->span * sizeof(double), stream);
+    } else {
+        fa_hip_memcpy_h2d(o + L->lo, re + L->lo, (size_t)L->span * sizeof(double), stream);
+    }
+}
+static void stage_d2h(const stage_layout *L, double *st, double *re, i64 im, void *stream) {
+    double *o = stage_origin(L, st);
+    if (L->two) {
+        fa_hip_memcpy_d2h(re + L->lo, o + L->lo, (size_t)L->span * sizeof(double), stream);
+        fa_hip_memcpy_d2h(re + im + L->lo, o + L->im_dev + L->lo, (size_t)L->span * sizeof(double), stream);
+    } else {
+        fa_hip_memcpy_d2h(re + L->lo, o + L->lo, (size_t)L->span * sizeof(double), stream);
+    }
 }
 
 static double *stage_buf(double **slot, size_t *have, size_t need) {
@@ -1904,9 +1956,10 @@ void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
 static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *io) {
     double *bufs[FA_MAXBUF];
     void *tabs[FA_MAXTAB];
-    int i, in_host = 0, out_host = 0;
+    int i, in_host = 0, out_host = 0, host_inplace = 0;
     i64 cs;
-    i64 in_im = ii - ri, out_im = io - ro;
+    i64 in_im = ii - ri, out_im = io - ro, out_im_host = 0;
+    stage_layout Lin, Lout;
     double *din = ri, *dout = ro;
     i64 in_span_lo = p->in_lo, in_span_hi = p->in_hi;
     i64 out_span_lo = p->out_lo, out_span_hi = p->out_hi;
@@ -1917,33 +1970,48 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
     if (FA_REAL_IN(p->type)) in_im = 0;
     if (FA_REAL_OUT(p->type)) out_im = 0;
 
-    /* plain host arrays are staged through device copies (slow path, PCIe) */
+    /* plain host arrays are staged through device copies (slow path, PCIe).  A split array whose
+       imaginary plane lies beyond the real one (|im| >= span: typically two separate allocations,
+       the usual fftw_plan_guru_split_dft call) is staged as two packed planes -- never as one span
+       from the lower to the upper plane, which would read and write whatever the caller keeps
+       between the two allocations. */
     in_host = !fa_hip_is_device_ptr(ri);
     out_host = !fa_hip_is_device_ptr(ro);
+    Lin = stage_layout_of(in_span_lo, in_span_hi, in_im);
+    Lout = stage_layout_of(out_span_lo, out_span_hi, out_im);
+    host_inplace = in_host && out_host && ro == ri && (io == ii || FA_REAL_OUT(p->type) || FA_REAL_IN(p->type));
+    if (host_inplace) {
+        /* both views share one staging image: same plane layout, union of the spans */
+        if (Lin.two != Lout.two || (Lin.two && (Lin.lo != Lout.lo || Lin.hi != Lout.hi || Lin.im_dev != Lout.im_dev))) {
+            fprintf(stderr, "fftw3_amd: in-place execution on host arrays whose input and output views have "
+                            "different split layouts is not supported\n");
+            abort();
+        }
+        if (!Lin.two) {
+            if (Lout.lo < Lin.lo) Lin.lo = Lout.lo;
+            if (Lout.hi > Lin.hi) Lin.hi = Lout.hi;
+            Lin.span = Lin.hi - Lin.lo + 1;
+            Lout.lo = Lin.lo; Lout.hi = Lin.hi; Lout.span = Lin.span;
+        }
+    }
     if (in_host) {
-        /* one contiguous span covering real and imaginary parts */
-        i64 lo = in_span_lo, hi = in_span_hi;
-        size_t bytes;
-        if (in_im > 0) hi += in_im; else lo += in_im;
-        bytes = (size_t)(hi - lo + 1) * sizeof(double);
-        din = stage_buf(&p->stage_in, &p->stage_in_bytes, bytes);
-        fa_hip_memcpy_h2d(din, ri + lo, bytes, p->stream);
-        din -= lo;
+        double *st = stage_buf(&p->stage_in, &p->stage_in_bytes, stage_bytes(&Lin));
+        stage_h2d(&Lin, st, ri, in_im, p->stream);
+        din = stage_origin(&Lin, st);
+        in_im = Lin.im_dev;
     }
     if (out_host) {
-        i64 lo = out_span_lo, hi = out_span_hi;
-        size_t bytes;
-        if (out_im > 0) hi += out_im; else lo += out_im;
-        bytes = (size_t)(hi - lo + 1) * sizeof(double);
-        if (in_host && ro == ri && io == ii) {
-            dout = din;                           /* in place */
+        if (host_inplace) {
+            dout = din;
         } else {
-            dout = stage_buf(&p->stage_out, &p->stage_out_bytes, bytes);
+            double *st = stage_buf(&p->stage_out, &p->stage_out_bytes, stage_bytes(&Lout));
             /* gaps between output elements must survive the round trip */
-            if ((i64)(bytes / sizeof(double)) != p->out_written)
-                fa_hip_memcpy_h2d(dout, ro + lo, bytes, p->stream);
-            dout -= lo;
+            if ((i64)(stage_bytes(&Lout) / sizeof(double)) != p->out_written)
+                stage_h2d(&Lout, st, ro, out_im, p->stream);
+            dout = stage_origin(&Lout, st);
         }
+        out_im_host = out_im;
+        out_im = Lout.im_dev;
     }
 
     bufs[0] = din;
@@ -1951,76 +2019,6 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
     for (i = 2; i < p->nbufs; ++i) bufs[i] = p->dbuf[i];
     for (i = 0; i < p->ntabs; ++i) tabs[i] = p->tabs[i].dev;
 
-    if (p->fused_err_host && p->fused_err_host[0]) {
-        fprintf(stderr, "fftw3_amd: fused kernel reported a synchronisation timeout (%d)\n", p->fused_err_host[0]);
-        abort();
-    }
-    if (p->mixed && fa_hip_is_device_ptr(ri) && fa_hip_is_device_ptr(ro) && ii == ri + 1 && io == ro + 1) {
-        const fftw_amd_step_desc *s1 = &p->steps[1];
-        const i64 C = p->mixed_chunk, nch = (p->batch + C - 1) / C, slot_doubles = C * ((i64)2 << 20);
-        int flags = (p->sign > 0) ? (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT) : 0;
-        void *e0 = NULL, *e1 = NULL;
-        i64 k;
-        if (g_prof_ms) { e0 = fa_hip_event_create(); e1 = fa_hip_event_create(); fa_hip_event_record(e0, p->stream); }
-        for (k = 0; k <= nch; ++k) {
-            /* launch k: pass 1 of chunk k, pass 2 of chunk k-1 */
-            int n1 = k < nch ? (int)((p->batch - k * C < C) ? p->batch - k * C : C) : 0;
-            int n2 = k >= 1 ? (int)((p->batch - (k - 1) * C < C) ? p->batch - (k - 1) * C : C) : 0;
-            fa_hip_launch_mixed1024(bufs[0] + k * C * p->hdims[0].is, bufs[1] + (k - 1) * C * p->hdims[0].os,
-                                    p->fused_scratch + (k & 1) * slot_doubles,
-                                    p->fused_scratch + ((k + 1) & 1) * slot_doubles,
-                                    p->hdims[0].is, p->hdims[0].os, n1, n2, flags,
-                                    tabs[s1->table], tabs[s1->tw_lo], tabs[s1->tw_hi], s1->tw_shift, p->stream);
-        }
-        if (g_prof_ms) {
-            fa_hip_event_record(e1, p->stream);
-            fa_hip_stream_sync(p->stream);
-            g_prof_ms[0] += (double)fa_hip_event_elapsed_ms(e0, e1);
-            g_prof_launches[0] += nch + 1;
-            fa_hip_event_destroy(e0);
-            fa_hip_event_destroy(e1);
-        }
-        return;
-    }
-    if (p->fused && !p->mixed && fa_hip_is_device_ptr(ri) && fa_hip_is_device_ptr(ro) && ii == ri + 1 && io == ro + 1) {
-        const fftw_amd_step_desc *s1 = &p->steps[1];
-        void *e0 = NULL, *e1 = NULL;
-        int flags = (p->sign > 0) ? (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT) : 0;
-        if (g_prof_ms) { e0 = fa_hip_event_create(); e1 = fa_hip_event_create(); fa_hip_event_record(e0, p->stream); }
-        if (fa_hip_launch_fused1024(bufs[0], bufs[1], p->fused_scratch, p->fused_slots, p->fused_lag,
-                                    p->hdims[0].is, p->hdims[0].os, p->batch, flags,
-                                    tabs[s1->table], tabs[s1->tw_lo], tabs[s1->tw_hi], s1->tw_shift,
-                                    p->fused_ctrl, p->stream) == 0) {
-            if (p->fused_err_host)
-                fa_hip_memcpy_d2h(p->fused_err_host, p->fused_ctrl + 2 * p->batch + 2, sizeof(int), p->stream);
-            if (getenv("FFTW_AMD_FUSED_DEBUG")) {
-                int *h = (int *)malloc(sizeof(int) * (size_t)(2 * p->batch + 16));
-                i64 k, lo1 = 1 << 30, hi1 = 0, lo2 = 1 << 30, hi2 = 0;
-                fa_hip_memcpy_d2h(h, p->fused_ctrl, sizeof(int) * (size_t)(2 * p->batch + 16), p->stream);
-                fa_hip_stream_sync(p->stream);
-                for (k = 0; k < p->batch; ++k) {
-                    if (h[k] < lo1) lo1 = h[k];
-                    if (h[k] > hi1) hi1 = h[k];
-                    if (h[p->batch + k] < lo2) lo2 = h[p->batch + k];
-                    if (h[p->batch + k] > hi2) hi2 = h[p->batch + k];
-                }
-                fprintf(stderr, "fused: ticket=%d error=%d done1=[%lld,%lld] done2=[%lld,%lld] "
-                        "slot-waits blocked=%d spins=%d  pass2-waits blocked=%d spins=%d\n",
-                        h[2 * p->batch], h[2 * p->batch + 2], lo1, hi1, lo2, hi2,
-                        h[2 * p->batch + 4], h[2 * p->batch + 5], h[2 * p->batch + 6], h[2 * p->batch + 7]);
-                free(h);
-            }
-            if (g_prof_ms) {
-                fa_hip_event_record(e1, p->stream);
-                fa_hip_stream_sync(p->stream);
-                g_prof_ms[0] += (double)fa_hip_event_elapsed_ms(e0, e1);
-                g_prof_launches[0] += 1;
-                fa_hip_event_destroy(e0);
-                fa_hip_event_destroy(e1);
-            }
-            return;
-        }
-    }
     {
         i64 nchunks = (p->batch + p->chunk - 1) / p->chunk, ev = 0, c = 0;
         void **events = NULL;
@@ -2080,13 +2078,7 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
         }
     }
 
-    if (out_host) {
-        i64 lo = out_span_lo, hi = out_span_hi;
-        size_t bytes;
-        if (out_im > 0) hi += out_im; else lo += out_im;
-        bytes = (size_t)(hi - lo + 1) * sizeof(double);
-        fa_hip_memcpy_d2h(ro + lo, dout + lo, bytes, p->stream);
-    }
+    if (out_host) stage_d2h(&Lout, host_inplace ? p->stage_in : p->stage_out, ro, out_im_host, p->stream);
     if (in_host || out_host) fa_hip_stream_sync(p->stream);
 }
 

@@ -150,7 +150,7 @@ fftw_plan fftw_plan_guru64_split_dft_c2r(int rank, const fftw_iodim64 *dims,
                                          int howmany_rank, const fftw_iodim64 *howmany_dims,
                                          double *ri, double *ii, double *out, unsigned flags);
 
-/* ---- r2r planners: symbols only, always NULL (reference fftw/fftw3.h:328-372) ---- */
+/* ---- r2r planners (reference fftw/fftw3.h:328-372) ---- */
 fftw_plan fftw_plan_many_r2r(int rank, const int *n, int howmany,
                              double *in, const int *inembed, int istride, int idist,
                              double *out, const int *onembed, int ostride, int odist,

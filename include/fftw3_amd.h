@@ -142,8 +142,10 @@ enum {
     FFTW_AMD_F_TW_IN     = 1 << 9, /* pass: the twiddle multiplies the INPUT element (l, q) instead of the output */
     FFTW_AMD_F_R2C_ROWS  = 1 << 10,/* pass over real pairs (src_im = 1) that also does the r2c untangle for n = 2L:
                                       stores L + 1 entries per row; tw_lo / tw_hi hold w_n^m (tw_n stays 0) */
-    FFTW_AMD_F_C2R_ROWS  = 1 << 11 /* the transpose: reads L + 1 spectrum entries per row, c2r tangle, backward
+    FFTW_AMD_F_C2R_ROWS  = 1 << 11,/* the transpose: reads L + 1 spectrum entries per row, c2r tangle, backward
                                       length-L pass, stores the real pairs (dst_im = 1) */
+    FFTW_AMD_F_NT_IN     = 1 << 12,/* the source is read once per execution: nontemporal loads */
+    FFTW_AMD_F_NT_OUT    = 1 << 13 /* the destination is not read again by this plan: nontemporal stores */
 };
 
 int fftw_amd_plan_num_steps(const fftw_plan p);

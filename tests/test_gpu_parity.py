@@ -708,3 +708,110 @@ def test_inplace_padded_real_transforms(torch_dev, shape):
     torch.cuda.synchronize()
     got = bd.cpu().numpy()[..., :n]
     assert aerror(got, x * np.prod(shape)) < TOL, q.sprint()
+
+
+def _far_apart(n, rng=None, fill=None):
+    """two independently allocated host arrays with at least one unrelated allocation between
+    them (a guard block that must come back untouched)"""
+    a = np.empty(n)
+    guard = np.full(4096, 1234.5)
+    b = np.empty(n)
+    if rng is not None:
+        a[:] = rng.random(n) - 0.5
+        b[:] = rng.random(n) - 0.5
+    elif fill is not None:
+        a[:] = fill
+        b[:] = fill
+    return a, b, guard
+
+
+def test_split_host_arrays_from_separate_allocations(torch_dev):
+    """fftw_plan_guru_split_dft with ri / ii (ro / io) in different heap blocks, the usual way the
+    split interface is called: the staging path must move the two planes separately (it used to copy
+    ONE span from the lower to the upper plane -- everything in between, both ways).  c2c, r2c and c2r,
+    through fftw_execute and the new-array split executes."""
+    rng = np.random.default_rng(77)
+    n, b = 1536, 3
+    dims, hm = [(n, 1, 1)], [(b, n, n)]
+    # ---- c2c
+    ri, ii, g1 = _far_apart(n * b, rng)
+    ro, io, g2 = _far_apart(n * b, fill=0.0)
+    x = (ri + 1j * ii).reshape(b, n)
+    want = oracle_dft(x, (n,), b).reshape(b, n)
+    p = fa.plan_guru64_split_dft(dims, hm, ri, ii, ro, io)
+    p.execute()
+    assert aerror((ro + 1j * io).reshape(b, n), want) < TOL
+    ri2, ii2, g3 = _far_apart(n * b, rng)
+    ro2, io2, g4 = _far_apart(n * b, fill=0.0)
+    p.execute_split_dft(ri2, ii2, ro2, io2)
+    assert aerror((ro2 + 1j * io2).reshape(b, n), oracle_dft((ri2 + 1j * ii2).reshape(b, n), (n,), b).reshape(b, n)) < TOL
+    # in place on the two planes
+    ri3, ii3 = ri.copy(), ii.copy()
+    q = fa.plan_guru64_split_dft(dims, hm, ri3, ii3, ri3, ii3)
+    q.execute()
+    assert aerror((ri3 + 1j * ii3).reshape(b, n), want) < TOL
+    # ---- r2c: real input, split half spectrum (n/2+1 per row)
+    nh = n // 2 + 1
+    xr = rng.random((b, n)) - 0.5
+    cro, cio, g5 = _far_apart(nh * b, fill=0.0)
+    pr = fa.plan_guru64_split_dft_r2c([(n, 1, 1)], [(b, n, nh)], xr, cro, cio)
+    pr.execute()
+    wantr = oracle_r2c(xr, (n,), b).reshape(b, nh)
+    assert aerror((cro + 1j * cio).reshape(b, nh), wantr) < TOL
+    cro2, cio2, g6 = _far_apart(nh * b, fill=0.0)
+    xr2 = rng.random((b, n)) - 0.5
+    pr.execute_split_dft_r2c(xr2, cro2, cio2)
+    assert aerror((cro2 + 1j * cio2).reshape(b, nh), oracle_r2c(xr2, (n,), b).reshape(b, nh)) < TOL
+    # ---- c2r: split half spectrum in, real out (input is destroyed: work on copies)
+    sre, sim_, g7 = _far_apart(nh * b)
+    sre[:] = wantr.real.reshape(-1)
+    sim_[:] = wantr.imag.reshape(-1)
+    back = np.zeros((b, n))
+    pc = fa.plan_guru64_split_dft_c2r([(n, 1, 1)], [(b, nh, n)], sre, sim_, back)
+    pc.execute()
+    assert aerror(back / n, xr) < TOL
+    sre2, sim2, g8 = _far_apart(nh * b)
+    sre2[:] = wantr.real.reshape(-1)
+    sim2[:] = wantr.imag.reshape(-1)
+    back2 = np.zeros((b, n))
+    pc.execute_split_dft_c2r(sre2, sim2, back2)
+    assert aerror(back2 / n, xr) < TOL
+    for g in (g1, g2, g3, g4, g5, g6, g7, g8):
+        assert np.all(g == 1234.5), "memory between the two planes was overwritten"
+
+
+def test_unaligned_flag_and_new_array_execute_on_8_byte_offset(torch_dev):
+    """FFTW_UNALIGNED (reference genus predicates, fftw/dft_simd/common/genus.c:26-331: a SIMD
+    codelet may only run on aligned arrays; fftw_execute_dft needs the plan's alignment unless the
+    plan was made with FFTW_UNALIGNED, A.c:433).  Here: a plan made with FFTW_UNALIGNED must run
+    on arrays that are only 8-byte aligned, for every kernel family the planner would pick."""
+    torch, dev = torch_dev
+    rng = np.random.default_rng(5)
+    for n, b in ((1024, 16), (4096, 4), (360, 9), (1 << 16, 2), (2000, 3), (97, 5)):
+        x = crand(rng, b, n)
+        want = oracle_dft(x, (n,), b).reshape(b, n)
+        al = torch.zeros(b * n * 2 + 8, dtype=torch.float64, device=dev)
+        ao = torch.zeros(b * n * 2 + 8, dtype=torch.float64, device=dev)
+        p = fa.plan_many_dft(1, [n], b, al, None, 1, n, ao, None, 1, n, fa.FORWARD, fa.ESTIMATE | fa.UNALIGNED)
+        # 8 bytes off a 16-byte boundary
+        xin = al[1:1 + 2 * b * n]
+        xout = ao[1:1 + 2 * b * n]
+        assert xin.data_ptr() % 16 == 8 and xout.data_ptr() % 16 == 8
+        xin.copy_(torch.from_numpy(x.view(np.float64).reshape(-1)))
+        p.execute_dft(xin, xout)
+        torch.cuda.synchronize()
+        got = xout.cpu().numpy().view(np.complex128).reshape(b, n)
+        assert aerror(got, want) < TOL, n
+    # real transforms: the fused rows kernels have no unaligned form, so the flag must steer the plan
+    n, b = 1024, 8
+    xr = rrand(rng, b, n)
+    al = torch.zeros(b * n + 8, dtype=torch.float64, device=dev)
+    ao = torch.zeros(b * (n // 2 + 1) * 2 + 8, dtype=torch.float64, device=dev)
+    p = fa.plan_many_dft_r2c(1, [n], b, al, None, 1, n, ao, None, 1, n // 2 + 1, fa.ESTIMATE | fa.UNALIGNED)
+    xin = al[1:1 + b * n]
+    xout = ao[1:1 + 2 * b * (n // 2 + 1)]
+    xin.copy_(torch.from_numpy(xr.reshape(-1)))
+    p.execute_dft_r2c(xin, xout)
+    torch.cuda.synchronize()
+    got = xout.cpu().numpy().view(np.complex128).reshape(b, n // 2 + 1)
+    assert aerror(got, oracle_r2c(xr, (n,), b).reshape(b, n // 2 + 1)) < TOL

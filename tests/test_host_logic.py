@@ -411,3 +411,24 @@ def test_stock_c_client_compiles_and_links_as_libfftw3(tmp_path):
                     "-L", libdir, "-lfftw3", "-Wl,-rpath," + libdir, "-lm", "-o", str(exe)], check=True)
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0 and "client ok" in r.stdout and "rdft-r2r" in r.stdout, r.stdout
+
+
+def test_wisdom_key_of_rank8_plan_with_huge_strides_stays_in_bounds():
+    """the wisdom key is built from every dim's (n, is, os): eight dims of 18-digit strides used to
+    run past a 320-byte stack buffer (snprintf returns the would-be length) -- "stack smashing
+    detected" before any planning.  Keys must also stay distinct when only a late stride differs."""
+    big = 10 ** 17
+    x = np.zeros(16, dtype=complex)
+    y = np.zeros(16, dtype=complex)
+    for hm in ([], [(2, 8, 8)]):
+        for rank in (7, 8):
+            dims = [(1, big + i, big - i) for i in range(rank - 1)] + [(8, 1, 1)]
+            try:
+                p = fa.plan_guru64_dft(dims, hm, x, y, fa.FORWARD, fa.ESTIMATE)
+            except ValueError:
+                continue                 # more loop dims than the executor carries: NULL, not a crash
+            assert p.handle and p.sprint()
+    fa.forget_wisdom()
+    dims = [(1, big + i, big - i) for i in range(7)] + [(8, 1, 1)]
+    p = fa.plan_guru64_dft(dims, [], x, y, fa.FORWARD, fa.ESTIMATE)
+    run_plan_on_host(p, x, y)
