@@ -81,55 +81,230 @@ def workload(name, batch_override):
 
 
 def pmc_traffic(step, units):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
+    """(HBM bytes per launch of the dominant kernel, source) from the committed PMC passes
+    (profiles/r0x_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
     FETCH_SIZE doubled as the MI355X guide prescribes).  Counters cannot be read inside
-    this process; the per-transform figure measured on the same kernel is scaled to the
-    transforms one launch processes.  None when the kernel has no committed measurement."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if step.L != 1024 or step.variant != 1 or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        prof = json.load(f)
-    key = "pass1024_kernel<false, true, 2>" if step.tw_n else "pass1024_kernel<true, true, 0>"
-    for name, v in prof["kernels"].items():
-        if key in name:
-            return v["traffic_bytes_per_transform"] * units
-    return None
+    this process: the per-transform figure measured on the same kernel is scaled to the
+    transforms one launch processes, and `traffic_source` says so.  (None, None) when the
+    kernel has no committed measurement."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if step.L != 1024 or step.variant != 1 or not os.path.exists(path):
+            continue
+        with open(path) as f:
+            prof = json.load(f)
+        key = "pass1024_kernel<false, true, 2" if step.tw_n else "pass1024_kernel<true, true, 0"
+        for kname, v in prof["kernels"].items():
+            if key in kname:
+                return v["traffic_bytes_per_transform"] * units, "profiles/%s (static: rocprofv3 --pmc passes of the same kernel, scaled per launch)" % name
+    return None, None
 
 
-def cpu_baseline(n, kind, flops_per_transform, target_seconds=12.0):
-    """the oracle (a port, one core) on a bounded sample of the same workload"""
-    import numpy as np
-    from util import oracle_dft, oracle_r2c, oracle_r2r
-    rng = np.random.default_rng(1)
-    size = int(np.prod(n))
-    if kind == "c2c":
-        x = (rng.random(size) - 0.5) + 1j * (rng.random(size) - 0.5)
-        run = lambda: oracle_dft(x, tuple(n), 1)
-    elif kind == "r2r":
-        x = rng.random(size) - 0.5
-        run = lambda: oracle_r2r(x, list(n), [5] * len(n))
-    else:
-        x = rng.random(size) - 0.5
-        run = lambda: oracle_r2c(x, tuple(n), 1)
-    run()                                   # builds the oracle's twiddle cache
-    t0 = time.perf_counter()
-    run()
-    one = time.perf_counter() - t0
-    reps = max(1, min(256, int(target_seconds / max(one, 1e-6))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        run()
+# reference numbers measured by the survey on this container's CPU (BASELINE.md section 2): the
+# port below is NOT FFTW's speed
+CPU_NOTE = ("the oracle is a plain-C restatement (kind 'port'); the reference itself measured on the survey "
+            "container at n=2^20: 3.16 GFLOPS scalar build, 8.27 GFLOPS AVX+FFTW_MEASURE, one core (BASELINE.md section 2)")
+
+_CPU_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+core, kind, seconds = int(sys.argv[2]), sys.argv[3], float(sys.argv[4])
+n = [int(v) for v in sys.argv[5].split("x")]
+try:
+    os.sched_setaffinity(0, {core})
+except Exception:
+    pass
+import numpy as np
+from util import oracle_dft, oracle_r2c, oracle_r2r
+rng = np.random.default_rng(1 + core)
+size = int(np.prod(n))
+if kind == "c2c":
+    x = (rng.random(size) - 0.5) + 1j * (rng.random(size) - 0.5)
+    run = lambda: oracle_dft(x, tuple(n), 1)
+elif kind == "r2r":
+    x = rng.random(size) - 0.5
+    run = lambda: oracle_r2r(x, list(n), [5] * len(n))
+else:
+    x = rng.random(size) - 0.5
+    run = lambda: oracle_r2c(x, tuple(n), 1)
+run()
+print("ready", flush=True)
+sys.stdin.readline()                      # start gun: every worker times the same window
+t0 = time.perf_counter(); reps = 0
+while True:
+    run(); reps += 1
     dt = time.perf_counter() - t0
-    return {
-        "value": flops_per_transform * reps / dt / 1e9,
-        "unit": "GFLOPS",
-        "cores": 1,
-        "kind": "port",
-        "sample": "%d transforms of n=%s (oracle/fftw_oracle.c, 1 thread, %.1f s)" % (
-            reps, "x".join(str(v) for v in n), dt),
+    if dt >= seconds:
+        break
+print("%d %.6f" % (reps, dt), flush=True)
+"""
+
+
+def cpu_baseline(n, kind, flops_per_transform, target_seconds=8.0, all_cores=True):
+    """The oracle (kind "port": a plain-C restatement of the reference path) on the host cores of
+    this box, on a bounded sample of the same workload: P pinned worker processes, each transforming
+    its own share of the batch (the batch shards trivially, SURVEY.md 8d: "P independent processes,
+    each planning howmany/P transforms"), all timing the same window.  Primary value: ONE core;
+    `all_cores`: every core this process may use (capped at 16, the GPU box's CPU share)."""
+    import subprocess
+    import tempfile
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except Exception:
+        cores = list(range(os.cpu_count() or 1))
+    size = 1
+    for v in n:
+        size *= v
+    # every worker holds its input, output and the oracle's tables: keep the whole leg under ~8 GiB
+    cap = max(1, min(16, int((8 << 30) // (size * 16 * 6 + 1))))
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(_CPU_WORKER)
+        script = f.name
+
+    def measure(use):
+        procs = [subprocess.Popen([sys.executable, script, ROOT, str(c), kind, str(target_seconds),
+                                   "x".join(str(v) for v in n)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                  text=True, env=dict(os.environ, OMP_NUM_THREADS="1")) for c in use]
+        try:
+            for pr in procs:
+                if pr.stdout.readline().strip() != "ready":
+                    raise RuntimeError("cpu baseline worker failed to start")
+            for pr in procs:
+                pr.stdin.write("go\n")
+                pr.stdin.flush()
+            reps, worst = 0, 0.0
+            for pr in procs:
+                r, dt = pr.stdout.readline().split()
+                reps += int(r)
+                worst = max(worst, float(dt))
+            for pr in procs:
+                pr.wait(timeout=30)
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        return reps, worst
+
+    try:
+        reps1, dt1 = measure(cores[:1])
+        out = {
+            "value": flops_per_transform * reps1 / dt1 / 1e9, "unit": "GFLOPS", "cores": 1, "kind": "port",
+            "sample": "%d transforms of n=%s (oracle/fftw_oracle.c, 1 pinned process, %.1f s)" % (
+                reps1, "x".join(str(v) for v in n), dt1),
+            "note": CPU_NOTE,
+        }
+        use = cores[:cap]
+        if all_cores and len(use) > 1:
+            repsP, dtP = measure(use)
+            out["all_cores"] = {
+                "value": flops_per_transform * repsP / dtP / 1e9, "unit": "GFLOPS", "cores": len(use), "kind": "port",
+                "sample": "%d transforms of n=%s over %d pinned processes, one share of the batch each, %.1f s" % (
+                    repsP, "x".join(str(v) for v in n), len(use), dtP),
+            }
+    finally:
+        os.unlink(script)
+    return out
+
+
+def run_workload(name, batch_override, steps, warmup, torch, fa, dist, world, rank, dev, want_cpu, cpu_seconds=8.0):
+    """One BASELINE config on this rank's GPU: plan, W warm-ups, K timed executions between
+    barriers (wall clock, max over ranks) plus a HIP-event pair around every single step for
+    min / median, the per-launch roofline of the dominant kernel, and the CPU baseline."""
+    n, b, kind, flops1, abytes1 = workload(name, batch_override)
+    size = 1
+    for v in n:
+        size *= v
+    # shrink the batch if this GPU cannot hold input + output + scratch
+    free, _ = torch.cuda.mem_get_info()
+    per = (32 if kind == "c2c" else 8 + 17) * size
+    while b > 1 and b * per + (1 << 30) > free:
+        b //= 2
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)
+    if kind == "c2c":
+        x = torch.empty((b, size), dtype=torch.complex128, device=dev)
+        xr = torch.view_as_real(x)
+        step_rows = max(1, (1 << 28) // size)
+        for r0 in range(0, b, step_rows):        # uniform [-0.5, 0.5), filled in slabs
+            sl = xr[r0:r0 + step_rows]
+            sl.copy_(torch.rand(sl.shape, dtype=torch.float64, device=dev, generator=gen) - 0.5)
+        y = torch.empty_like(x)
+        plan = fa.plan_many_dft(len(n), n, b, x, None, 1, size, y, None, 1, size, fa.FORWARD,
+                                fa.ESTIMATE)
+    elif kind == "r2r":
+        x = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
+        y = torch.empty_like(x)
+        plan = fa.plan_many_r2r(len(n), n, b, x, None, 1, size, y, None, 1, size,
+                                [fa.REDFT10] * len(n), fa.ESTIMATE)
+    else:
+        hs = size // n[-1] * (n[-1] // 2 + 1)
+        x = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
+        y = torch.empty((b, hs), dtype=torch.complex128, device=dev)
+        plan = fa.plan_many_dft_r2c(len(n), n, b, x, None, 1, size, y, None, 1, hs, fa.ESTIMATE)
+    plan.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        plan.execute()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()                     # torch's current stream IS the stream the plan launches on
+        plan.execute()
+        e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_transforms = b * world * steps
+    gflops = flops1 * total_transforms / dt / 1e9
+    alg_gbs = abytes1 * total_transforms / dt / 1e9
+
+    # ---- roofline of the dominant kernel: HIP events around every launch
+    prof = plan.execute_profiled()
+    torch.cuda.synchronize()
+    roof = None
+    if prof:
+        dom = max(prof, key=lambda t: t[1])
+        st, ms, launches = dom
+        avg_ms = ms / max(1, launches)
+        units = min(plan.chunk, plan.batch)           # transforms one launch processes
+        # a pass reads every element of its chunk once and writes it once
+        # (r2r: every step of the REDFT10 plan moves n reals in and n reals out per transform,
+        # the half-length complex passes included)
+        bytes_per_launch = abytes1 * units
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic, source = pmc_traffic(st, units)
+        roof = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+            "kernel": "step%d kind=%d L=%d variant=%d" % (prof.index(dom), st.kind, st.L, st.variant),
+            "avg_launch_ms": avg_ms, "launches_per_step": launches,
+            "alg_bytes_per_launch": bytes_per_launch,
+            "whole_transform_GBs": alg_gbs / world, "whole_transform_frac": alg_gbs / world / HBM_PEAK_GBS,
+            "steps_ms": [round(t[1], 4) for t in prof],
+        }
+    res = {
+        "workload": name, "kind": kind, "n": n, "howmany": b, "size": size, "flops1": flops1, "abytes1": abytes1,
+        "gflops": gflops, "alg_gbs": alg_gbs, "ms_per_step": dt / steps * 1e3,
+        "ms_min": step_ms[0], "ms_median": step_ms[len(step_ms) // 2],
+        "plan": plan.sprint().replace("\n", " "), "roofline": roof, "free": free,
     }
+    res["_y"] = y
+    if want_cpu:
+        res["cpu_baseline"] = cpu_baseline(n, kind, flops1, target_seconds=cpu_seconds)
+    del plan, x
+    return res
 
 
 def run_slab(args, torch, fa, dist, world, rank, dev):
@@ -261,6 +436,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU howmany override")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="headline workload only (no r2c / mixed / 2d legs)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -298,85 +474,10 @@ def main():
     if args.workload == "slab2d":
         return run_slab(args, torch, fa, dist, world, rank, dev)
 
-    n, b, kind, flops1, abytes1 = workload(args.workload, args.batch)
-    size = 1
-    for v in n:
-        size *= v
-    # shrink the batch if this GPU cannot hold input + output + scratch
-    free, _ = torch.cuda.mem_get_info()
-    per = (32 if kind == "c2c" else 8 + 17) * size
-    while b > 1 and b * per + (1 << 30) > free:
-        b //= 2
-
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1 + rank)
-    if kind == "c2c":
-        x = torch.empty((b, size), dtype=torch.complex128, device=dev)
-        xr = torch.view_as_real(x)
-        step_rows = max(1, (1 << 28) // size)
-        for r0 in range(0, b, step_rows):        # uniform [-0.5, 0.5), filled in slabs
-            sl = xr[r0:r0 + step_rows]
-            sl.copy_(torch.rand(sl.shape, dtype=torch.float64, device=dev, generator=gen) - 0.5)
-        y = torch.empty_like(x)
-        plan = fa.plan_many_dft(len(n), n, b, x, None, 1, size, y, None, 1, size, fa.FORWARD,
-                                fa.ESTIMATE)
-    elif kind == "r2r":
-        x = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
-        y = torch.empty_like(x)
-        plan = fa.plan_many_r2r(len(n), n, b, x, None, 1, size, y, None, 1, size,
-                                [fa.REDFT10] * len(n), fa.ESTIMATE)
-    else:
-        hs = size // n[-1] * (n[-1] // 2 + 1)
-        x = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
-        y = torch.empty((b, hs), dtype=torch.complex128, device=dev)
-        plan = fa.plan_many_dft_r2c(len(n), n, b, x, None, 1, size, y, None, 1, hs, fa.ESTIMATE)
-    plan.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        plan.execute()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        plan.execute()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    total_transforms = b * world * args.steps
-    gflops = flops1 * total_transforms / dt / 1e9
-    alg_gbs = abytes1 * total_transforms / dt / 1e9
-
-    # ---- roofline of the dominant kernel: HIP events around every launch
-    prof = plan.execute_profiled()
-    torch.cuda.synchronize()
-    roof = None
-    if prof:
-        dom = max(prof, key=lambda t: t[1])
-        st, ms, launches = dom
-        avg_ms = ms / max(1, launches)
-        units = min(plan.chunk, plan.batch)           # transforms one launch processes
-        # a pass reads every element of its chunk once and writes it once
-        # (r2r: every step of the REDFT10 plan moves n reals in and n reals out per transform,
-        # the half-length complex passes included)
-        bytes_per_launch = abytes1 * units
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roof = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(st, units),
-            "kernel": "step%d kind=%d L=%d variant=%d" % (prof.index(dom), st.kind, st.L, st.variant),
-            "avg_launch_ms": avg_ms, "launches_per_step": launches,
-            "alg_bytes_per_launch": bytes_per_launch,
-            "whole_transform_GBs": alg_gbs / world, "whole_transform_frac": alg_gbs / world / HBM_PEAK_GBS,
-            "steps_ms": [round(t[1], 4) for t in prof],
-        }
+    res = run_workload(args.workload, args.batch, args.steps, args.warmup, torch, fa, dist, world, rank, dev,
+                       want_cpu=(world == 1 and rank == 0 and not args.no_cpu_baseline))
+    y = res.pop("_y")
+    n, b, kind, size, free = res["n"], res["howmany"], res["kind"], res["size"], res["free"]
 
     gather = None
     if args.gather and dist is not None:
@@ -384,32 +485,61 @@ def main():
         gb = min(b, max(1, (int(free * 0.35) // (16 * size)) // world))
         src = y[:gb].contiguous()
         dst = torch.empty((world * gb, y.shape[1]), dtype=y.dtype, device=dev)
-        barrier()
+        dist.barrier()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         dist.all_gather_into_tensor(torch.view_as_real(dst), torch.view_as_real(src))
-        barrier()
+        dist.barrier()
+        torch.cuda.synchronize()
         tg = time.perf_counter() - t0
         gather = {"seconds": tg, "bytes_received_per_rank": (world - 1) * src.numel() * 16,
                   "GBs_per_rank": (world - 1) * src.numel() * 16 / tg / 1e9}
+        del src, dst
+    del y
+    torch.cuda.empty_cache()
+
+    # ---- the other BASELINE configs, one GPU, same measurement (reported as legs, never as `value`)
+    legs = []
+    if world == 1 and args.workload == "c2c" and not args.no_legs and not args.batch:
+        for name in ("r2c", "mixed", "2d"):
+            lr = run_workload(name, 0, max(3, args.steps // 2), 1, torch, fa, None, 1, 0, dev,
+                              want_cpu=not args.no_cpu_baseline, cpu_seconds=4.0)
+            lr.pop("_y")
+            torch.cuda.empty_cache()
+            legs.append({
+                "workload": "%s n=%s howmany=%d, forward, out-of-place, FFTW_ESTIMATE" % (
+                    lr["kind"], "x".join(str(v) for v in lr["n"]), lr["howmany"]),
+                "baseline_config": {"r2c": "configs[2]", "mixed": "configs[3] (sub-batch 256 of 2048: 504 GB per array do not fit one GPU)",
+                                    "2d": "configs[4] (one GPU's share of 512 images on 8 GPUs)"}[name],
+                "value": lr["gflops"], "unit": "GFLOPS", "ms_per_step": lr["ms_per_step"],
+                "ms_min": lr["ms_min"], "ms_median": lr["ms_median"], "algorithmic_GBs": lr["alg_gbs"],
+                "plan": lr["plan"],
+                "roofline": None if lr["roofline"] is None else {k: lr["roofline"][k] for k in (
+                    "bound", "achieved", "peak", "unit", "frac", "whole_transform_frac", "kernel", "avg_launch_ms", "steps_ms")},
+                "cpu_baseline": lr.get("cpu_baseline"),
+            })
 
     if rank == 0:
         out = {
             "metric": "GFLOPS (5N*log2N) + achieved HBM GB/s, 1D complex double N=2^20 batch=4096"
             if args.workload == "c2c" else "GFLOPS (reference mflops formula), workload " + args.workload,
-            "value": gflops, "unit": "GFLOPS", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "value": res["gflops"], "unit": "GFLOPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "ms_per_step_min": res["ms_min"], "ms_per_step_median": res["ms_median"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s n=%s howmany=%d per GPU, forward, out-of-place, FFTW_ESTIMATE" % (
                 kind, "x".join(str(v) for v in n), b),
-                "algorithmic_GBs": alg_gbs, "parallelism": "batch-sharded x%d" % world,
-                "plan": plan.sprint().replace("\n", " ")},
-            "roofline": roof,
+                "algorithmic_GBs": res["alg_gbs"], "parallelism": "batch-sharded x%d" % world,
+                "plan": res["plan"]},
+            "roofline": res["roofline"],
         }
+        if legs:
+            out["config"]["legs"] = legs
         if gather:
             out["all_gather"] = gather
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, kind, flops1)
+        if "cpu_baseline" in res:
+            out["cpu_baseline"] = res["cpu_baseline"]
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
