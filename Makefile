@@ -9,7 +9,7 @@ LIBDIR := fftw3_amd/lib
 CFLAGS := -O2 -fPIC -std=gnu99 -Wall -Wextra -Iinclude -I$(CSRC)
 HIPFLAGS := -O3 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -std=c++17 -Wall
 
-OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/hostmath.o $(CSRC)/kernels.o $(CSRC)/kernels_rr.o $(CSRC)/kernels_r3.o
+OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/sharded.o $(CSRC)/hostmath.o $(CSRC)/kernels.o $(CSRC)/kernels_rr.o $(CSRC)/kernels_r3.o
 
 all: $(LIBDIR)/libfftw3_amd.so
 
@@ -21,7 +21,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_
 
 $(LIBDIR)/libfftw3_amd.so: $(OBJS)
 	mkdir -p $(LIBDIR)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lm -lpthread
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -lm -lpthread -ldl
 	ln -sf libfftw3_amd.so $(LIBDIR)/libfftw3.so.3
 	ln -sf libfftw3_amd.so $(LIBDIR)/libfftw3.so
 

@@ -134,6 +134,22 @@ _sig("fftw_plan_guru64_split_dft_c2r", _vp, C.c_int, C.POINTER(iodim64), C.c_int
      _vp, _vp, _vp, C.c_uint)
 _sig("fftw_execute_split_dft_r2c", None, _vp, _vp, _vp, _vp)
 _sig("fftw_execute_split_dft_c2r", None, _vp, _vp, _vp, _vp)
+_vpp = C.POINTER(C.c_void_p)
+_sig("fftw_amd_shard_range", None, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
+_sig("fftw_amd_plan_many_dft_sharded", _vp, C.c_int, _ip, C.c_int, C.c_int, _ip, _vpp, _ip, C.c_int, C.c_int,
+     _vpp, _ip, C.c_int, C.c_int, C.c_int, C.c_uint)
+_sig("fftw_amd_plan_many_dft_r2c_sharded", _vp, C.c_int, _ip, C.c_int, C.c_int, _ip, _vpp, _ip, C.c_int, C.c_int,
+     _vpp, _ip, C.c_int, C.c_int, C.c_uint)
+_sig("fftw_amd_plan_many_dft_c2r_sharded", _vp, C.c_int, _ip, C.c_int, C.c_int, _ip, _vpp, _ip, C.c_int, C.c_int,
+     _vpp, _ip, C.c_int, C.c_int, C.c_uint)
+_sig("fftw_amd_execute_sharded", None, _vp)
+_sig("fftw_amd_sharded_sync", None, _vp)
+_sig("fftw_amd_sharded_all_gather", C.c_int, _vp, _vpp, C.c_int)
+_sig("fftw_amd_sharded_num_shards", C.c_int, _vp)
+_sig("fftw_amd_sharded_device", C.c_int, _vp, C.c_int)
+_sig("fftw_amd_sharded_range", None, _vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
+_sig("fftw_amd_sharded_replica", _vp, _vp, C.c_int)
+_sig("fftw_amd_destroy_sharded_plan", None, _vp)
 _sig("fftw_execute_r2r", None, _vp, _vp, _vp)
 _sig("fftw_plan_r2r", _vp, C.c_int, _ip, _vp, _vp, _ip, C.c_uint)
 _sig("fftw_plan_r2r_1d", _vp, C.c_int, _vp, _vp, C.c_int, C.c_uint)
@@ -467,6 +483,98 @@ def plan_guru64_dft_r2c(dims, howmany_dims, i, o, flags=ESTIMATE):
 def plan_guru64_dft_c2r(dims, howmany_dims, i, o, flags=ESTIMATE):
     return Plan(lib.fftw_plan_guru64_dft_c2r(len(dims), _iodims(dims), len(howmany_dims),
                                              _iodims(howmany_dims), ptr(i), ptr(o), flags), (i, o))
+
+
+def shard_range(howmany, nshards, g):
+    """block rule of the C layer (fftw_amd_shard_range): [g*ceil(B/P), min(B, (g+1)*ceil(B/P)))"""
+    lo, hi = C.c_longlong(0), C.c_longlong(0)
+    lib.fftw_amd_shard_range(howmany, nshards, g, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def _ptrs(arrays):
+    return (C.c_void_p * len(arrays))(*[ptr(a) for a in arrays])
+
+
+class ShardedPlan(object):
+    """fftw_amd_plan_many_dft*_sharded: one batched transform cut over several GPUs inside the C library
+    (one plan replica, stream and host thread per device)."""
+
+    def __init__(self, handle, keep):
+        if not handle:
+            raise ValueError("sharded planner returned NULL (invalid or unsupported problem)")
+        self.handle = handle
+        self._keep = keep
+
+    def execute(self):
+        if device_count() <= 0:
+            raise RuntimeError("no HIP device: the sharded plan cannot execute (no CPU fallback)")
+        lib.fftw_amd_execute_sharded(self.handle)
+
+    def sync(self):
+        lib.fftw_amd_sharded_sync(self.handle)
+
+    def all_gather(self, full, mode=0):
+        """full[d]: whole-batch buffer on shard d's device.  Returns 1 (RCCL), 0 (peer-to-peer)."""
+        self._keep_full = full
+        rc = lib.fftw_amd_sharded_all_gather(self.handle, _ptrs(full), mode)
+        if rc < 0:
+            raise RuntimeError("all-gather of the output shards failed")
+        return rc
+
+    @property
+    def num_shards(self):
+        return lib.fftw_amd_sharded_num_shards(self.handle)
+
+    def device(self, g):
+        return lib.fftw_amd_sharded_device(self.handle, g)
+
+    def range(self, g):
+        lo, hi = C.c_longlong(0), C.c_longlong(0)
+        lib.fftw_amd_sharded_range(self.handle, g, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def replica_sprint(self, g):
+        h = lib.fftw_amd_sharded_replica(self.handle, g)
+        if not h:
+            return None
+        s = lib.fftw_sprint_plan(h)
+        try:
+            return C.cast(s, C.c_char_p).value.decode()
+        finally:
+            lib.fftw_free(s)
+
+    def destroy(self):
+        if self.handle:
+            lib.fftw_amd_destroy_sharded_plan(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def plan_many_dft_sharded(rank, n, howmany, devs, ins, inembed, istride, idist, outs, onembed, ostride, odist,
+                          sign, flags=ESTIMATE):
+    return ShardedPlan(lib.fftw_amd_plan_many_dft_sharded(rank, _ints(n), howmany, len(ins), _ints(devs), _ptrs(ins),
+                                                          _ints(inembed), istride, idist, _ptrs(outs), _ints(onembed),
+                                                          ostride, odist, sign, flags), (ins, outs))
+
+
+def plan_many_dft_r2c_sharded(rank, n, howmany, devs, ins, inembed, istride, idist, outs, onembed, ostride, odist,
+                              flags=ESTIMATE):
+    return ShardedPlan(lib.fftw_amd_plan_many_dft_r2c_sharded(rank, _ints(n), howmany, len(ins), _ints(devs), _ptrs(ins),
+                                                              _ints(inembed), istride, idist, _ptrs(outs),
+                                                              _ints(onembed), ostride, odist, flags), (ins, outs))
+
+
+def plan_many_dft_c2r_sharded(rank, n, howmany, devs, ins, inembed, istride, idist, outs, onembed, ostride, odist,
+                              flags=ESTIMATE):
+    return ShardedPlan(lib.fftw_amd_plan_many_dft_c2r_sharded(rank, _ints(n), howmany, len(ins), _ints(devs), _ptrs(ins),
+                                                              _ints(inembed), istride, idist, _ptrs(outs),
+                                                              _ints(onembed), ostride, odist, flags), (ins, outs))
 
 
 def cexp(m, n):

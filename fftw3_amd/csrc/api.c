@@ -844,6 +844,17 @@ void *fftw_amd_malloc_device(size_t nbytes) {
     return fa_hip_malloc(nbytes);
 }
 void fftw_amd_free_device(void *p) { fa_hip_free(p); }
+/* blocking copies, so that a plain C caller of the device path needs no HIP headers */
+void fftw_amd_memcpy_to_device(void *dst_device, const void *src_host, size_t nbytes) {
+    if (!nbytes || fa_hip_device_count() <= 0) return;
+    fa_hip_memcpy_h2d(dst_device, src_host, nbytes, NULL);
+    fa_hip_stream_sync(NULL);
+}
+void fftw_amd_memcpy_to_host(void *dst_host, const void *src_device, size_t nbytes) {
+    if (!nbytes || fa_hip_device_count() <= 0) return;
+    fa_hip_memcpy_d2h(dst_host, src_device, nbytes, NULL);
+    fa_hip_stream_sync(NULL);
+}
 void fftw_amd_plan_set_stream(fftw_plan p, void *s) { if (p) p->stream = s; }
 void fftw_amd_plan_sync(fftw_plan p) { if (p && fa_hip_device_count() > 0) fa_hip_stream_sync(p->stream); }
 

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 
 #define FA_DEV __device__ __forceinline__
 #include "butterflies.h"
@@ -25,6 +26,18 @@ typedef long long i64;
             abort();                                                                \
         }                                                                           \
     } while (0)
+
+/* Function attributes (dynamic LDS size) are per device: a "done" flag is a bit mask over the
+   device ordinals, so that a process that drives several GPUs (sharded plans, one host thread
+   per device) sets them on each.  Setting twice is harmless; the bit is published after the
+   attribute, so no thread can launch on a device before the attribute is there. */
+static inline unsigned fa_dev_bit(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return 1u << (dev & 31);
+}
+static inline bool fa_attr_needed(const std::atomic<unsigned> &mask) { return !(mask.load(std::memory_order_acquire) & fa_dev_bit()); }
+static inline void fa_attr_set(std::atomic<unsigned> &mask) { mask.fetch_or(fa_dev_bit(), std::memory_order_release); }
 
 /* ------------------------------------------------------------------------ */
 /* element access helpers                                                    */

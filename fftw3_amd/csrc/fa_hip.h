@@ -35,6 +35,10 @@ void  fa_hip_event_destroy(void *ev);
 void *fa_hip_stream_create(void);                   /* non-blocking stream */
 void  fa_hip_stream_destroy(void *stream);
 void  fa_hip_stream_wait_event(void *stream, void *ev);
+int   fa_hip_get_device(void);
+void  fa_hip_set_device(int dev);                   /* of the calling host thread */
+int   fa_hip_enable_peer(int dev, int peer);        /* 0: dev may address peer's memory */
+void  fa_hip_memcpy_peer(void *dst, int dst_dev, const void *src, int src_dev, size_t nbytes, void *stream);
 
 /* Launch one step.  bufs[i] is the device base pointer of buffer id i, tables[i]
    the device pointer of table id i.  (chunk_start, chunk_n) select the slice

@@ -129,6 +129,9 @@ struct fftw_plan_s {
     size_t stage_in_bytes, stage_out_bytes;
 
     double est_flops;
+
+    double *prof_ms;            /* fftw_amd_execute_profiled: per-step sinks, NULL otherwise */
+    long long *prof_launches;
 };
 
 /* hostmath.c */

@@ -844,6 +844,24 @@ extern "C" void *fa_hip_stream_create(void) {
     return (void *)s;
 }
 extern "C" void fa_hip_stream_destroy(void *s) { FA_CHECK(hipStreamDestroy((hipStream_t)s)); }
+extern "C" int fa_hip_get_device(void) { int d = 0; FA_CHECK(hipGetDevice(&d)); return d; }
+extern "C" void fa_hip_set_device(int dev) { FA_CHECK(hipSetDevice(dev)); }
+/* 0 on success; a missing peer path is not an error (hipMemcpyPeerAsync stages through the host then) */
+extern "C" int fa_hip_enable_peer(int dev, int peer) {
+    int can = 0, cur = 0;
+    if (dev == peer) return 0;
+    FA_CHECK(hipGetDevice(&cur));
+    if (hipDeviceCanAccessPeer(&can, dev, peer) != hipSuccess || !can) { (void)hipGetLastError(); return 1; }
+    FA_CHECK(hipSetDevice(dev));
+    hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+    if (e != hipSuccess) (void)hipGetLastError();            /* hipErrorPeerAccessAlreadyEnabled included */
+    FA_CHECK(hipSetDevice(cur));
+    return (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ? 0 : 1;
+}
+extern "C" void fa_hip_memcpy_peer(void *dst, int dst_dev, const void *src, int src_dev, size_t n, void *stream) {
+    if (dst_dev == src_dev) FA_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    else FA_CHECK(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, n, (hipStream_t)stream));
+}
 extern "C" void fa_hip_stream_wait_event(void *s, void *ev) {
     FA_CHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0));
 }
@@ -857,7 +875,7 @@ static void grid_for(i64 total, dim3 *grid) {
 }
 
 
-static int g_lds_attr_done = 0;
+static std::atomic<unsigned> g_lds_attr_done{0};
 
 template <bool VIN, bool VOUT>
 static void launch_pass_variant(const PassArgs &pa, dim3 grid, size_t lds, hipStream_t st) {
@@ -880,12 +898,12 @@ int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *con
 
 template <bool IN_T, bool OUT_T, int HAS_TW>
 static void launch_p1024_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
-    static bool attr_done = false;
+    static std::atomic<unsigned> attr_done{0};
     const size_t lds = FA_P1024_LDS_DOUBLES * sizeof(double);
-    if (!attr_done) {
+    if (fa_attr_needed(attr_done)) {
         FA_CHECK(hipFuncSetAttribute((const void *)pass1024_kernel<IN_T, OUT_T, HAS_TW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        fa_attr_set(attr_done);
     }
     hipLaunchKernelGGL((pass1024_kernel<IN_T, OUT_T, HAS_TW>), grid, dim3(256), lds, st, pa);
 }
@@ -1015,7 +1033,7 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
         fprintf(stderr, "fftw3_amd: internal error: pass tile needs %zu B of LDS\n", lds);
         return -1;
     }
-    if (!g_lds_attr_done) {
+    if (fa_attr_needed(g_lds_attr_done)) {
         FA_CHECK(hipFuncSetAttribute((const void *)pass_generic_kernel<false, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FA_CHECK(hipFuncSetAttribute((const void *)pass_generic_kernel<true, false>,
@@ -1024,7 +1042,7 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         FA_CHECK(hipFuncSetAttribute((const void *)pass_generic_kernel<true, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_lds_attr_done = 1;
+        fa_attr_set(g_lds_attr_done);
     }
     /* 16-byte vector access when the element is an aligned interleaved pair */
     bool vin = d->src_im == 1 && !(d->flags & FFTW_AMD_F_REAL_IN) &&
@@ -1048,14 +1066,14 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
                 d->radices[i] == 12 || d->radices[i] == 14 || d->radices[i] == 15) small_radices = false;
         /* ping-pong images that fit twice on a CU need no help; larger tiles take the single image */
         if (inplace_mode && small_radices && (i64)pa.L * pa.T <= 4096 && lds > 80 * 1024) {
-            static bool done = false;
+            static std::atomic<unsigned> done{0};
             size_t lds1 = (size_t)pa.L * pa.ld * sizeof(cplx);
-            if (!done) {
+            if (fa_attr_needed(done)) {
                 FA_CHECK(hipFuncSetAttribute((const void *)pass_inplace_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 FA_CHECK(hipFuncSetAttribute((const void *)pass_inplace_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 FA_CHECK(hipFuncSetAttribute((const void *)pass_inplace_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 FA_CHECK(hipFuncSetAttribute((const void *)pass_inplace_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                done = true;
+                fa_attr_set(done);
             }
             if (vin && vout) hipLaunchKernelGGL((pass_inplace_kernel<true, true>), grid, dim3(256), lds1, st, pa);
             else if (vin) hipLaunchKernelGGL((pass_inplace_kernel<true, false>), grid, dim3(256), lds1, st, pa);

@@ -13,13 +13,13 @@
 
 template <int R1, int R2, int R3>
 static void launch_3g(const P3SArgs &pa, dim3 grid, hipStream_t st) {
-    static bool attr_done = false;
+    static std::atomic<unsigned> attr_done{0};
     static_assert(P3GGeom<R1, R2, R3>::fits, "menu entry exceeds the per-item element budget");
     const size_t lds = P3GGeom<R1, R2, R3>::lds_doubles * sizeof(double);
-    if (!attr_done) {
+    if (fa_attr_needed(attr_done)) {
         FA_CHECK(hipFuncSetAttribute((const void *)pass3g_kernel<R1, R2, R3>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        fa_attr_set(attr_done);
     }
     hipLaunchKernelGGL((pass3g_kernel<R1, R2, R3>), grid, dim3(256), lds, st, pa);
 }
@@ -83,13 +83,13 @@ int fa_launch_pass3g(const fftw_amd_step_desc *d, double *const *bufs, void *con
 
 template <int R1, int R2, int R3, bool IN_T, int TW>
 static void launch_3t_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
-    static bool attr_done = false;
+    static std::atomic<unsigned> attr_done{0};
     static_assert(P3TGeom<R1, R2, R3>::fits, "menu entry exceeds the per-item element budget");
     const size_t lds = P3TGeom<R1, R2, R3>::lds_doubles * sizeof(double);
-    if (!attr_done) {
+    if (fa_attr_needed(attr_done)) {
         FA_CHECK(hipFuncSetAttribute((const void *)pass3t_kernel<R1, R2, R3, IN_T, TW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        fa_attr_set(attr_done);
     }
     hipLaunchKernelGGL((pass3t_kernel<R1, R2, R3, IN_T, TW>), grid, dim3(256), lds, st, pa);
 }
@@ -176,14 +176,14 @@ int fa_launch_pass3t(const fftw_amd_step_desc *d, double *const *bufs, void *con
 
 template <int R1, int R2>
 static void launch_r2cr(const R2CRArgs &ra, dim3 grid, hipStream_t st, bool inverse) {
-    static bool attr_done = false;
+    static std::atomic<unsigned> attr_done{0};
     const size_t lds = R2CRGeom<R1, R2>::lds_doubles * sizeof(double);
-    if (!attr_done) {
+    if (fa_attr_needed(attr_done)) {
         FA_CHECK(hipFuncSetAttribute((const void *)r2crows_kernel<R1, R2>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FA_CHECK(hipFuncSetAttribute((const void *)c2rrows_kernel<R1, R2>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        fa_attr_set(attr_done);
     }
     if (inverse) hipLaunchKernelGGL((c2rrows_kernel<R1, R2>), grid, dim3(256), lds, st, ra);
     else hipLaunchKernelGGL((r2crows_kernel<R1, R2>), grid, dim3(256), lds, st, ra);

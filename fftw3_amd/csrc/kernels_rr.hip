@@ -13,12 +13,12 @@
 
 template <int R1, int R2, bool IN_T, bool OUT_T, int TW>
 static void launch_rr_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
-    static bool attr_done = false;
+    static std::atomic<unsigned> attr_done{0};
     const size_t lds = RRGeom<R1, R2>::lds_doubles * sizeof(double);
-    if (!attr_done) {
+    if (fa_attr_needed(attr_done)) {
         FA_CHECK(hipFuncSetAttribute((const void *)passrr_kernel<R1, R2, IN_T, OUT_T, TW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        fa_attr_set(attr_done);
     }
     hipLaunchKernelGGL((passrr_kernel<R1, R2, IN_T, OUT_T, TW>), grid, dim3(256), lds, st, pa);
 }
@@ -107,12 +107,12 @@ int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *con
 
 template <int R1>
 static void launch_3s(const P3SArgs &pa, dim3 grid, hipStream_t st) {
-    static bool attr_done = false;
+    static std::atomic<unsigned> attr_done{0};
     const size_t lds = P3SGeom<R1>::lds_doubles * sizeof(double);
-    if (!attr_done) {
+    if (fa_attr_needed(attr_done)) {
         FA_CHECK(hipFuncSetAttribute((const void *)pass3s_kernel<R1>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        fa_attr_set(attr_done);
     }
     hipLaunchKernelGGL((pass3s_kernel<R1>), grid, dim3(256), lds, st, pa);
 }

@@ -1939,9 +1939,9 @@ static double *stage_buf(double **slot, size_t *have, size_t need) {
     return *slot;
 }
 
-/* per-step HIP-event timing of one execution: set by fftw_amd_execute_profiled */
-static double *g_prof_ms = NULL;
-static long long *g_prof_launches = NULL;
+/* per-step HIP-event timing of one execution: p->prof_ms / p->prof_launches, set by
+   fftw_amd_execute_profiled under the plan's lock (never process-wide: another plan's
+   execute on another thread must not see them) */
 
 static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *io);
 
@@ -2023,7 +2023,7 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
         i64 nchunks = (p->batch + p->chunk - 1) / p->chunk, ev = 0, c = 0;
         void **events = NULL;
         const int pipe = p->nslots > 1;
-        if (g_prof_ms) events = (void **)malloc(sizeof(void *) * (size_t)(2 * nchunks * p->nsteps));
+        if (p->prof_ms) events = (void **)malloc(sizeof(void *) * (size_t)(2 * nchunks * p->nsteps));
         if (pipe) {
             /* the side streams start after everything already queued on the caller's stream */
             fa_hip_event_record(p->ev_begin, p->stream);
@@ -2068,8 +2068,8 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
             ev = 0;
             for (c = 0; c < nchunks; ++c)
                 for (i = 0; i < p->nsteps; ++i) {
-                    g_prof_ms[i] += (double)fa_hip_event_elapsed_ms(events[ev], events[ev + 1]);
-                    g_prof_launches[i] += 1;
+                    p->prof_ms[i] += (double)fa_hip_event_elapsed_ms(events[ev], events[ev + 1]);
+                    p->prof_launches[i] += 1;
                     fa_hip_event_destroy(events[ev]);
                     fa_hip_event_destroy(events[ev + 1]);
                     ev += 2;
@@ -2089,11 +2089,13 @@ int fftw_amd_execute_profiled(fftw_plan p, double *ms, long long *launches, int 
     int i;
     if (!p || cap < p->nsteps) return -1;
     for (i = 0; i < p->nsteps; ++i) { ms[i] = 0.0; launches[i] = 0; }
-    g_prof_ms = ms;
-    g_prof_launches = launches;
-    fa_run(p, p->ri, p->ii, p->ro, p->io);
-    g_prof_ms = NULL;
-    g_prof_launches = NULL;
+    pthread_mutex_lock(&p->lock);
+    p->prof_ms = ms;
+    p->prof_launches = launches;
+    fa_run_locked(p, p->ri, p->ii, p->ro, p->io);
+    p->prof_ms = NULL;
+    p->prof_launches = NULL;
+    pthread_mutex_unlock(&p->lock);
     return p->nsteps;
 }
 

@@ -25,6 +25,10 @@ int fftw_amd_device_count(void);
    returns pinned host memory so CPU callers keep working (staged path). */
 void *fftw_amd_malloc_device(size_t nbytes);
 void  fftw_amd_free_device(void *p);
+/* Blocking host <-> device copies (hipMemcpy), so that a C caller of the device path needs no
+   HIP headers of its own. */
+void  fftw_amd_memcpy_to_device(void *dst_device, const void *src_host, size_t nbytes);
+void  fftw_amd_memcpy_to_host(void *dst_host, const void *src_device, size_t nbytes);
 
 /* Bind the HIP stream (hipStream_t as void*) that fftw_execute* launches on.
    NULL restores the default stream.  Per plan. */
@@ -43,6 +47,54 @@ size_t fftw_amd_plan_workspace_bytes(const fftw_plan p);
    (profiles/r01_membw.txt), while they pay more launches.  0 restores the
    default.  Affects plans created afterwards. */
 void fftw_amd_set_chunk_bytes(size_t nbytes);
+
+/* ---- batch sharding over the GPUs of one node ----------------------
+   The reference splits the vector loop of a batched plan across its workers inside the library
+   (fftw/threads/dft-vrank-geq1.c:140-175, block size ceil(vl / nthr) :158-159; the same block
+   rule as fftw/mpi/block.c:35-42).  Here the workers are GPUs: shard g of ndev owns the
+   transforms [g*ceil(B/ndev), min(B, (g+1)*ceil(B/ndev))) of the batch, with one plan replica
+   (tables + scratch), one stream and one host thread per device, and nothing exchanged inside a
+   transform.  in[g] / out[g] are device pointers on device devs[g] (devs == NULL: 0..ndev-1)
+   that hold shard g -- its first transform at offset 0 -- laid out exactly as
+   fftw_plan_many_dft describes one batch (embed, stride, dist).  A device may appear more than
+   once in devs (its shards then run on separate streams of that device). */
+typedef struct fftw_amd_sharded_plan_s *fftw_amd_sharded_plan;
+
+void fftw_amd_shard_range(long long howmany, int nshards, int g, long long *lo, long long *hi);
+
+fftw_amd_sharded_plan fftw_amd_plan_many_dft_sharded(
+    int rank, const int *n, int howmany, int ndev, const int *devs,
+    fftw_complex *const *in, const int *inembed, int istride, int idist,
+    fftw_complex *const *out, const int *onembed, int ostride, int odist, int sign, unsigned flags);
+fftw_amd_sharded_plan fftw_amd_plan_many_dft_r2c_sharded(
+    int rank, const int *n, int howmany, int ndev, const int *devs,
+    double *const *in, const int *inembed, int istride, int idist,
+    fftw_complex *const *out, const int *onembed, int ostride, int odist, unsigned flags);
+fftw_amd_sharded_plan fftw_amd_plan_many_dft_c2r_sharded(
+    int rank, const int *n, int howmany, int ndev, const int *devs,
+    fftw_complex *const *in, const int *inembed, int istride, int idist,
+    double *const *out, const int *onembed, int ostride, int odist, unsigned flags);
+
+/* Enqueue every shard's transforms (asynchronous, like fftw_execute on device pointers);
+   fftw_amd_sharded_sync blocks until all devices are done. */
+void fftw_amd_execute_sharded(const fftw_amd_sharded_plan p);
+void fftw_amd_sharded_sync(const fftw_amd_sharded_plan p);
+
+/* All-gather of the output shards over xGMI: full[d] is a buffer on shard d's device for the
+   WHOLE batch (howmany * odist elements); every shard's output lands at its place in each of
+   them, ordered after the transforms (complete after fftw_amd_sharded_sync).  mode 0: RCCL
+   (librccl.so, loaded on first use; one ncclBroadcast per shard in a group, because block-rule
+   shards may differ in size) when every shard has its own device, direct peer-to-peer pushes
+   otherwise; 1: force peer-to-peer; 2: RCCL or fail.  Returns 1 if RCCL moved the data, 0 for
+   peer-to-peer, -1 on error.  This is the xGMI-bound part (for cfg5 each GPU
+   receives 120 GB at <= 7 x 153 GB/s) and is never part of a transform's timing. */
+int fftw_amd_sharded_all_gather(const fftw_amd_sharded_plan p, void *const *full, int mode);
+
+int  fftw_amd_sharded_num_shards(const fftw_amd_sharded_plan p);
+int  fftw_amd_sharded_device(const fftw_amd_sharded_plan p, int g);
+void fftw_amd_sharded_range(const fftw_amd_sharded_plan p, int g, long long *lo, long long *hi);
+fftw_plan fftw_amd_sharded_replica(const fftw_amd_sharded_plan p, int g);   /* NULL for an empty shard */
+void fftw_amd_destroy_sharded_plan(fftw_amd_sharded_plan p);
 
 /* ---- plan introspection used by the host-logic tests ------------------- */
 
