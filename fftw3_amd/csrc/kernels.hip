@@ -662,6 +662,52 @@ __global__ void __launch_bounds__(256) r2c_post4_kernel(const Real4Args a) {
     }
 }
 
+/* The same butterfly for the layout the large 1-D plans produce -- Z_0[k], Z_1[k] side by side
+   (32 contiguous bytes per k), interleaved complex output, no r2r epilogue, one loop dim (the
+   batch): 16-byte accesses, 32-bit index arithmetic, one work-item per pair (k, m-k), w^2k and
+   w^3k from w^k instead of four more table loads.  Pure streaming: 4 x 16 B in, 4 x 16 B out. */
+struct Real4Fast {
+    const double *src;
+    double *dst;
+    i64 sbatch, dbatch;   /* distance between transforms, in doubles */
+    unsigned m, npair;
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    int tw_shift;
+    int nt_out;
+};
+
+template <bool NT>
+__global__ void __launch_bounds__(256) r2c_post4_fast_kernel(const Real4Fast a) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= a.npair) return;
+    const unsigned m = a.m, km = k ? m - k : 0;
+    const double *s = a.src + (i64)blockIdx.y * a.sbatch;
+    double *d = a.dst + (i64)blockIdx.y * a.dbatch;
+    cplx w1 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (i64)k);
+    cplx zk0 = ld_cplx<false>(s + 4 * (i64)k), zk1 = ld_cplx<false>(s + 4 * (i64)k + 2);
+    cplx zm0 = ld_cplx<false>(s + 4 * (i64)km), zm1 = ld_cplx<false>(s + 4 * (i64)km + 2);
+    cplx T0 = c_make(0.5 * (zk0.x + zm0.x), 0.5 * (zk0.y - zm0.y));
+    cplx T1 = c_mni(c_make(0.5 * (zk0.x - zm0.x), 0.5 * (zk0.y + zm0.y)));
+    cplx T2 = c_make(0.5 * (zk1.x + zm1.x), 0.5 * (zk1.y - zm1.y));
+    cplx T3 = c_mni(c_make(0.5 * (zk1.x - zm1.x), 0.5 * (zk1.y + zm1.y)));
+    cplx w2 = c_mul(w1, w1), w3 = c_mul(w2, w1);
+    T1 = c_mulc(T1, w1);
+    T2 = c_mulc(T2, w2);
+    T3 = c_mulc(T3, w3);
+    cplx s02 = c_add(T0, T2), d02 = c_sub(T0, T2);
+    cplx s13 = c_add(T1, T3), d13 = c_sub(T1, T3);
+    cplx y0 = c_add(s02, s13);                 /* Y[k]       */
+    cplx y1 = c_add(d02, c_mni(d13));          /* Y[k+m]     */
+    cplx y2 = c_sub(s02, s13);  y2.y = -y2.y;  /* Y[2m-k]    */
+    cplx y3 = c_add(d02, c_mpi(d13)); y3.y = -y3.y;   /* Y[m-k] */
+    if (k == 0) { y0.y = 0.0; y2.y = 0.0; }
+    st_cplx<NT>(d + 2 * (i64)k, y0);
+    st_cplx<NT>(d + 2 * ((i64)k + m), y1);
+    st_cplx<NT>(d + 2 * (2 * (i64)m - k), y2);
+    if (k != 0 && 2 * k != m) st_cplx<NT>(d + 2 * ((i64)m - k), y3);
+}
+
 /* c2r: with A = Y[k], B = Y[k+m], C = conj Y[2m-k], D = conj Y[m-k]:
        S0 = A+B+C+D, S1 = A+iB-C-iD, S2 = A-B+C-D, S3 = A-iB-C+iD,
        X'_s = w_n^(-sk) S_s,  Z'_0[k] = X'_0 + i X'_1,  Z'_1[k] = X'_2 + i X'_3;
@@ -705,6 +751,33 @@ __global__ void __launch_bounds__(256) c2r_pre4_kernel(const Real4Args a) {
             store_elem<false>(a.dst, doff + (m - k) * a.os_k, a.dst_im, a.flags, z0);
             store_elem<false>(a.dst, doff + a.vs + (m - k) * a.os_k, a.dst_im, a.flags, z1);
         }
+    }
+}
+
+/* the transpose of r2c_post4_fast_kernel: interleaved half spectrum in, Z_0[k], Z_1[k] side by side out */
+template <bool NT>
+__global__ void __launch_bounds__(256) c2r_pre4_fast_kernel(const Real4Fast a) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= a.npair) return;
+    const unsigned m = a.m;
+    const double *s = a.src + (i64)blockIdx.y * a.sbatch;
+    double *d = a.dst + (i64)blockIdx.y * a.dbatch;
+    cplx w1 = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (i64)k);
+    cplx Yk = ld_cplx<NT>(s + 2 * (i64)k), Ykm = ld_cplx<NT>(s + 2 * ((i64)k + m));
+    cplx Y2 = ld_cplx<NT>(s + 2 * (2 * (i64)m - k)), Y1 = ld_cplx<NT>(s + 2 * ((i64)m - k));
+    if (k == 0) { Yk.y = 0.0; Y2.y = 0.0; }
+    cplx w2 = c_mul(w1, w1), w3 = c_mul(w2, w1);
+    cplx z0, z1;
+    c2r4_combine(Yk, Ykm, c_make(Y2.x, -Y2.y), c_make(Y1.x, -Y1.y), w1, w2, w3, &z0, &z1);
+    st_cplx<false>(d + 4 * (i64)k, z0);
+    st_cplx<false>(d + 4 * (i64)k + 2, z1);
+    if (k != 0 && 2 * k != m) {
+        cplx v1 = c_mpi(c_make(w1.x, -w1.y));
+        cplx v2 = c_make(-w2.x, w2.y);
+        cplx v3 = c_mni(c_make(w3.x, -w3.y));
+        c2r4_combine(Y1, Y2, c_make(Ykm.x, -Ykm.y), c_make(Yk.x, -Yk.y), v1, v2, v3, &z0, &z1);
+        st_cplx<false>(d + 4 * ((i64)m - k), z0);
+        st_cplx<false>(d + 4 * ((i64)m - k) + 2, z1);
     }
 }
 
@@ -1252,6 +1325,32 @@ static int launch_step_kind(const fftw_amd_step_desc *d, double *const *bufs,
         ra.tw_hi = (const cplx *)tables[d->tw_hi];
         ra.tw_shift = d->tw_shift;
         ra.flags = d->flags;
+        {
+            /* streaming form for the layout of the large 1-D plans (see r2c_post4_fast_kernel) */
+            const bool r2c = d->kind == FFTW_AMD_STEP_R2C_POST4;
+            const i64 zs = r2c ? ra.is_k : ra.os_k, ys = r2c ? ra.os_k : ra.is_k;   /* Z side / Y side strides */
+            const int swap_mask = FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_CONJ_OUT | FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT;
+            if (ra.r2r == 0 && ra.twmul == 1 && ra.src_im == 1 && ra.dst_im == 1 && zs == 4 && ys == 2 && ra.vs == 2 &&
+                !(d->flags & swap_mask) && d->ndims == 1 && bd == 0 && d->kpos == 0 && ra.m >= 2 && ra.m < (1LL << 30) &&
+                cn > 0 && cn < 65536 && (d->dim_is[0] % 2) == 0 && (d->dim_os[0] % 2) == 0 &&
+                ((uintptr_t)ra.src % 16) == 0 && ((uintptr_t)ra.dst % 16) == 0) {
+                Real4Fast fa4;
+                fa4.src = ra.src; fa4.dst = ra.dst;
+                fa4.sbatch = d->dim_is[0]; fa4.dbatch = d->dim_os[0];
+                fa4.m = (unsigned)ra.m; fa4.npair = (unsigned)ra.npair;
+                fa4.tw_lo = ra.tw_lo; fa4.tw_hi = ra.tw_hi; fa4.tw_shift = ra.tw_shift;
+                fa4.nt_out = 0;
+                dim3 g((fa4.npair + 255) / 256, (unsigned)cn, 1);
+                if (r2c) {
+                    if (d->flags & FFTW_AMD_F_NT_OUT) hipLaunchKernelGGL(r2c_post4_fast_kernel<true>, g, dim3(256), 0, st, fa4);
+                    else hipLaunchKernelGGL(r2c_post4_fast_kernel<false>, g, dim3(256), 0, st, fa4);
+                } else {
+                    if (d->flags & FFTW_AMD_F_NT_IN) hipLaunchKernelGGL(c2r_pre4_fast_kernel<true>, g, dim3(256), 0, st, fa4);
+                    else hipLaunchKernelGGL(c2r_pre4_fast_kernel<false>, g, dim3(256), 0, st, fa4);
+                }
+                return 0;
+            }
+        }
         dim3 grid;
         if (!elem_fill(&ra.e, d, ra.npair, cn, d->kpos, &grid)) return 0;
         if (d->kind == FFTW_AMD_STEP_R2C_POST4)
