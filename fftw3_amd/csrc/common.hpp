@@ -96,6 +96,54 @@ FA_DEV i64 fa_xcd_remap(i64 blk, i64 n) {
     return (blk & 7) * (n >> 3) + (blk >> 3);
 }
 
+/* runs of R complex values at a fixed stride, plain or nontemporal (FFTW_AMD_F_NT_IN / NT_OUT):
+   the policy is uniform over the launch, so the branch is scalar and each side is straight-line */
+template <int R> FA_DEV void ld_run(cplx *x, const double *p, i64 step, bool nt) {
+    if (nt) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) x[i] = ld_cplx<true>(p + i * step);
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i) x[i] = ld_cplx<false>(p + i * step);
+    }
+}
+FA_DEV void st_sel(double *p, cplx v, bool nt) {
+    if (nt) st_cplx<true>(p, v); else st_cplx<false>(p, v);
+}
+
+/* Block id -> (tile, offsets of the loop dims).  One-dimensional grids (every launch below 2^31
+   blocks) take the XCD-contiguous order and 32-bit arithmetic: a 64-bit division is ~130
+   instructions here, and this prologue sits in front of every workgroup's first load. */
+template <bool TW, class A>
+FA_DEV void fa_block_offsets(const A &a, i64 &tile, i64 &soff, i64 &doff, i64 &twb) {
+    soff = 0; doff = 0; twb = 0;
+    if (gridDim.y == 1) {
+        unsigned blk = (unsigned)fa_xcd_remap((i64)blockIdx.x, (i64)gridDim.x);
+        const unsigned nt = (unsigned)a.ntiles;
+        unsigned rest = blk / nt;
+        tile = blk - rest * nt;
+        for (int d = 1; d < a.ndims; ++d) {
+            const unsigned dn = (unsigned)a.dn[d];
+            const unsigned q = rest / dn, idx = rest - q * dn;
+            rest = q;
+            soff += (i64)idx * a.dis[d];
+            doff += (i64)idx * a.dos[d];
+            if constexpr (TW) twb += (i64)idx * a.dtw[d];
+        }
+    } else {
+        i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
+        tile = blk % a.ntiles;
+        i64 rest = blk / a.ntiles;
+        for (int d = 1; d < a.ndims; ++d) {
+            i64 idx = rest % a.dn[d];
+            rest /= a.dn[d];
+            soff += idx * a.dis[d];
+            doff += idx * a.dos[d];
+            if constexpr (TW) twb += idx * a.dtw[d];
+        }
+    }
+}
+
 /* w^m from the two-level table: (cos, sin)(2 pi m / n) */
 FA_DEV cplx tw2(const cplx *lo, const cplx *hi, int shift, i64 m) {
     cplx a = lo[m & ((1LL << shift) - 1)];

@@ -66,16 +66,8 @@ pass3g_kernel(const P3SArgs a) {
     constexpr int S1 = G::S1, A2S = G::A2S, SD2 = G::SD2;
     const int tid = threadIdx.x;
 
-    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
-    i64 tile = blk % a.ntiles;
-    i64 rest = blk / a.ntiles;
-    i64 soff = 0, doff = 0;
-    for (int d = 1; d < a.ndims; ++d) {
-        i64 idx = rest % a.dn[d];
-        rest /= a.dn[d];
-        soff += idx * a.dis[d];
-        doff += idx * a.dos[d];
-    }
+    i64 tile, soff, doff, twb_unused;
+    fa_block_offsets<false>(a, tile, soff, doff, twb_unused);
     const i64 t0 = tile * T;
     const int Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
     const double *src = a.src + soff + t0 * a.dis[0];
@@ -92,8 +84,7 @@ pass3g_kernel(const P3SArgs a) {
         at[u] = g / M;
         aa[u] = g - at[u] * M;
         const double *p = src + (i64)at[u] * a.dis[0] + 2 * aa[u];
-#pragma unroll
-        for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + (i64)i * (2 * M));
+        ld_run<R1>(x[u], p, (i64)(2 * M), (a.flags & FFTW_AMD_F_NT_IN) != 0);
     }
     if (a.flags & FFTW_AMD_F_SWAP_IN) {
 #pragma unroll
@@ -197,7 +188,7 @@ pass3g_kernel(const P3SArgs a) {
         for (int c = 0; c < R3; ++c) {
             cplx v = z[w][RB<R3>::slot(c)];
             if (sw) { double s = v.x; v.x = v.y; v.y = s; }
-            *reinterpret_cast<cplx *>(p + (i64)c * (2 * R1 * R2)) = v;
+            st_sel(p + (i64)c * (2 * R1 * R2), v, (a.flags & FFTW_AMD_F_NT_OUT) != 0);
         }
     }
 }
@@ -236,17 +227,8 @@ pass3t_kernel(const P1024Args a) {
     constexpr int M = G::M, T = G::T, QA = G::QA, QB = G::QB, QC = G::QC;
     const int tid = threadIdx.x;
 
-    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
-    i64 tile = blk % a.ntiles;
-    i64 rest = blk / a.ntiles;
-    i64 soff = 0, doff = 0, twb = 0;
-    for (int d = 1; d < a.ndims; ++d) {
-        i64 idx = rest % a.dn[d];
-        rest /= a.dn[d];
-        soff += idx * a.dis[d];
-        doff += idx * a.dos[d];
-        twb += idx * a.dtw[d];
-    }
+    i64 tile, soff, doff, twb;
+    fa_block_offsets<true>(a, tile, soff, doff, twb);
     const i64 t0 = tile * T;
     const int Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
     const double *src = a.src + soff + t0 * a.dis[0];
@@ -266,8 +248,7 @@ pass3t_kernel(const P1024Args a) {
         at[u] = t;
         const double *p = src + (i64)aa[u] * a.is_l + (i64)t * a.dis[0];
         const i64 step = (i64)M * a.is_l;
-#pragma unroll
-        for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + i * step);
+        ld_run<R1>(x[u], p, step, (a.flags & FFTW_AMD_F_NT_IN) != 0);
     }
     if (a.flags & FFTW_AMD_F_SWAP_IN) {
 #pragma unroll
@@ -395,7 +376,7 @@ pass3t_kernel(const P1024Args a) {
         for (int c = 0; c < R3; ++c) {
             cplx v = z[w][RB<R3>::slot(c)];
             if (sw) { double s = v.x; v.x = v.y; v.y = s; }
-            *reinterpret_cast<cplx *>(p + c * step) = v;
+            st_sel(p + c * step, v, (a.flags & FFTW_AMD_F_NT_OUT) != 0);
         }
     }
 }

@@ -50,16 +50,8 @@ pass3s_kernel(const P3SArgs a) {
     constexpr int T = G::T, S1 = G::S1, A2S = G::A2S, SD2 = G::SD2;
     const int tid = threadIdx.x;
 
-    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
-    i64 tile = blk % a.ntiles;
-    i64 rest = blk / a.ntiles;
-    i64 soff = 0, doff = 0;
-    for (int d = 1; d < a.ndims; ++d) {
-        i64 idx = rest % a.dn[d];
-        rest /= a.dn[d];
-        soff += idx * a.dis[d];
-        doff += idx * a.dos[d];
-    }
+    i64 tile, soff, doff, twb_unused;
+    fa_block_offsets<false>(a, tile, soff, doff, twb_unused);
     const i64 t0 = tile * T;
     const int Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
     const double *src = a.src + soff + t0 * a.dis[0];
@@ -71,8 +63,7 @@ pass3s_kernel(const P3SArgs a) {
     for (int t = 0; t < T; ++t) {
         const double *p = src + (i64)t * a.dis[0] + 2 * tid;
         if (t < Tcur) {
-#pragma unroll
-            for (int i = 0; i < R1; ++i) x[t][i] = *reinterpret_cast<const cplx *>(p + (i64)i * 512);
+            ld_run<R1>(x[t], p, 512, (a.flags & FFTW_AMD_F_NT_IN) != 0);
         } else {
 #pragma unroll
             for (int i = 0; i < R1; ++i) x[t][i] = c_make(0.0, 0.0);
@@ -179,7 +170,7 @@ pass3s_kernel(const P3SArgs a) {
             for (int c = 0; c < 16; ++c) {
                 cplx w = z[v][c];
                 if (sw) { double s = w.x; w.x = w.y; w.y = s; }
-                *reinterpret_cast<cplx *>(p + (i64)c * (32 * R1)) = w;
+                st_sel(p + (i64)c * (32 * R1), w, (a.flags & FFTW_AMD_F_NT_OUT) != 0);
             }
         }
     }

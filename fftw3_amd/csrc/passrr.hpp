@@ -150,8 +150,7 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
         const double *p = a.src + (i64)a1[u] * a.is_l + FA_TILE_SOFF(a, t1[u]);
         const i64 step = (i64)R2 * a.is_l;
         if (ok1[u] && (t1[u] >> a.lo_sh) < a.Tcur) {
-#pragma unroll
-            for (int i = 0; i < R1; ++i) x[u][i] = *reinterpret_cast<const cplx *>(p + i * step);
+            ld_run<R1>(x[u], p, step, (a.flags & FFTW_AMD_F_NT_IN) != 0);
         } else {
 #pragma unroll
             for (int i = 0; i < R1; ++i) x[u][i] = c_make(0.0, 0.0);
@@ -234,11 +233,12 @@ FA_DEV void prr_tile(const PRRTile &a, double *plane, const int tid) {
             double *p = a.dst + (i64)d2[v] * a.os_l + FA_TILE_DOFF(a, t2[v]);
             const i64 step = (i64)R1 * a.os_l;
             const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
+            const bool nt_out = (a.flags & FFTW_AMD_F_NT_OUT) != 0;
 #pragma unroll
             for (int c = 0; c < R2; ++c) {
                 cplx w = y[v][RB<R2>::slot(c)];
                 if (sw) { double s = w.x; w.x = w.y; w.y = s; }
-                *reinterpret_cast<cplx *>(p + c * step) = w;
+                st_sel(p + c * step, w, nt_out);
             }
         }
     }
@@ -250,17 +250,8 @@ __global__ void __launch_bounds__(256, fa_rr_wgs(R1, R2))
 passrr_kernel(const P1024Args a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
     constexpr int T = RRGeom<R1, R2>::T;
-    i64 blk = (i64)blockIdx.x + (i64)blockIdx.y * gridDim.x;
-    i64 tile = blk % a.ntiles;
-    i64 rest = blk / a.ntiles;
-    i64 soff = 0, doff = 0, twb = 0;
-    for (int d = 1; d < a.ndims; ++d) {
-        i64 idx = rest % a.dn[d];
-        rest /= a.dn[d];
-        soff += idx * a.dis[d];
-        doff += idx * a.dos[d];
-        twb += idx * a.dtw[d];
-    }
+    i64 tile, soff, doff, twb;
+    fa_block_offsets<true>(a, tile, soff, doff, twb);
     const i64 t0 = tile * (T >> a.lo_sh);
     PRRTile t;
     t.lo_sh = a.lo_sh; t.lo_is = a.lo_is; t.lo_os = a.lo_os;
