@@ -164,11 +164,11 @@ static plan *finish_locked(plan *p, double *ri, double *ii, double *ro, double *
             return NULL;
         } else if (!(p->flags & FFTW_ESTIMATE) && ri && ro && fa_hip_device_count() > 0) {
             /* FFTW_MEASURE / PATIENT / EXHAUSTIVE: time candidate configurations on the device */
-            static const size_t chunks[] = { (size_t)256 << 20, (size_t)1 << 30, (size_t)4 << 30 };
+            static const size_t chunks[] = { (size_t)128 << 20, (size_t)256 << 20, (size_t)512 << 20, (size_t)1 << 30, (size_t)4 << 30 };
             fa_cfg best = p->cfg, c;
             double best_ms = -1.0;
             int ci, pi, li, st, lf, nl = (p->flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1;
-            for (ci = 0; ci < 3; ++ci)
+            for (ci = 0; ci < 5; ++ci)
                 for (pi = 0; pi < 2; ++pi)
                     for (li = 0; li < nl; ++li)
                         for (st = 0; st < nl; ++st)
