@@ -778,6 +778,45 @@ static void pow2_three_pass_split(i64 n, i64 *lens) {
     lens[2] = (i64)1 << bc;
 }
 
+/* Three-pass split of a contiguous length that is not a power of two.  The balanced split the
+   factoriser returns is rarely the fastest: the register kernels differ by up to 1.5x from one
+   sub-transform length to the next (tile width, ragged tiles, radix mix) and by position (first:
+   long input stride; middle: in place; last: rows in, transposed out).  Costs are measured
+   medians, ms per GiB of a pass (split_costs.inc); the additive model picks the measured best
+   split for 5 of the 8 lengths it was checked on and is within 1-7 % on the others
+   (tools/perf/fit_split_costs.py).  Reference counterpart: the planner's choice among
+   ct-dit radices by estimated cost (fftw/fftw_api.c:15300-15426). */
+typedef struct { int L; double c[3]; } split_cost;
+static const split_cost g_split_costs[] = {
+#include "split_costs.inc"
+};
+static double split_cost_of(i64 L, int pos) {
+    const int n = (int)(sizeof(g_split_costs) / sizeof(g_split_costs[0]));
+    int i;
+    for (i = 0; i < n - 1; ++i)
+        if (g_split_costs[i].L == L && g_split_costs[i].c[pos] > 0.0) return g_split_costs[i].c[pos];
+    return g_split_costs[n - 1].c[pos];
+}
+static void mixed_three_pass_split(i64 n, i64 *lens) {
+    i64 a, c;
+    double best = -1.0;
+    for (a = 16; a <= 1024; ++a) {
+        if (n % a || !has_register_kernel(a)) continue;
+        for (c = 16; c <= 1024; ++c) {
+            i64 m, lo, hi;
+            double cost;
+            if ((n / a) % c || !has_register_kernel(c)) continue;
+            m = n / a / c;
+            if (m < 16 || m > 1024 || !has_register_kernel(m)) continue;
+            lo = a < c ? a : c; if (m < lo) lo = m;
+            hi = a > c ? a : c; if (m > hi) hi = m;
+            if (hi > 4 * lo) continue;
+            cost = split_cost_of(a, 0) + split_cost_of(m, 1) + split_cost_of(c, 2);
+            if (best < 0.0 || cost < best) { best = cost; lens[0] = a; lens[1] = m; lens[2] = c; }
+        }
+    }
+}
+
 static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     fa_axis ax = *ax_in;
     i64 lens[FA_MAXPASS];
@@ -827,6 +866,7 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     k = fa_factor_passes_pref(ax.n, FA_MAXPASS, lmax1, contiguous ? p->cfg.lmax_multi : FA_TILE_ELEMS / 8, lens,
                               getenv("FFTW_AMD_NO_TUNED") ? NULL : has_register_kernel);
     if (k == 3 && contiguous && (ax.n & (ax.n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) pow2_three_pass_split(ax.n, lens);
+    else if (k == 3 && contiguous && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_SPLIT_COSTS")) mixed_three_pass_split(ax.n, lens);
     {
         /* test hook: FFTW_AMD_FORCE_LENS="L1,L2,..." fixes the split of the axis whose length
            is the product (tests/test_gpu_menu.py reaches every kernel variant with it) */
