@@ -283,12 +283,21 @@ def run_workload(name, batch_override, steps, warmup, torch, fa, dist, world, ra
         # (r2r: every step of the REDFT10 plan moves n reals in and n reals out per transform,
         # the half-length complex passes included)
         bytes_per_launch = abytes1 * units
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        kernel = "step%d kind=%d L=%d variant=%d" % (prof.index(dom), st.kind, st.L, st.variant)
         traffic, source = pmc_traffic(st, units)
+        if plan.paired:
+            # one launch = pass 2 of chunk c-1 + pass 1 of chunk c: both passes' bytes, except that
+            # the first and the last of the nch + 1 launches hold one pass only
+            nch = (plan.batch + plan.chunk - 1) // plan.chunk
+            bytes_per_launch = 2.0 * abytes1 * units * nch / (nch + 1)
+            kernel = "pass1024_pair_kernel (pass 2 of chunk c-1 + pass 1 of chunk c in one launch)"
+            t2, _ = pmc_traffic(prof[1][0], units)
+            traffic = None if traffic is None or t2 is None else (traffic + t2) * nch / (nch + 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
-            "kernel": "step%d kind=%d L=%d variant=%d" % (prof.index(dom), st.kind, st.L, st.variant),
+            "kernel": kernel,
             "avg_launch_ms": avg_ms, "launches_per_step": launches,
             "alg_bytes_per_launch": bytes_per_launch,
             "whole_transform_GBs": alg_gbs / world, "whole_transform_frac": alg_gbs / world / HBM_PEAK_GBS,

@@ -177,6 +177,7 @@ _sig("fftw_amd_plan_set_stream", None, _vp, _vp)
 _sig("fftw_amd_plan_sync", None, _vp)
 _sig("fftw_amd_plan_workspace_bytes", C.c_size_t, _vp)
 _sig("fftw_amd_set_chunk_bytes", None, C.c_size_t)
+_sig("fftw_amd_plan_paired", C.c_int, _vp)
 _sig("fftw_amd_plan_num_steps", C.c_int, _vp)
 _sig("fftw_amd_plan_get_step", C.c_int, _vp, C.c_int, C.POINTER(StepDesc))
 _sig("fftw_amd_plan_chunk", C.c_longlong, _vp)
@@ -305,6 +306,10 @@ class Plan(object):
     @property
     def chunk(self):
         return lib.fftw_amd_plan_chunk(self.handle)
+
+    @property
+    def paired(self):
+        return bool(lib.fftw_amd_plan_paired(self.handle))
 
     @property
     def workspace_bytes(self):

@@ -47,6 +47,13 @@ int fa_hip_launch_step(const fftw_amd_step_desc *desc, double *const *bufs,
                        void *const *tables, long long chunk_start, long long chunk_n,
                        void *stream);
 
+/* One launch holding pass 2 (d_second) of one chunk and pass 1 (d_first) of the next one of the
+   batched 1024 x 1024 plan; either half may be empty (cn == 0).  1: the steps are not that pair. */
+int fa_hip_launch_pair1024(const fftw_amd_step_desc *d_second, double *const *bufs_second,
+                           long long cs2, long long cn2,
+                           const fftw_amd_step_desc *d_first, double *const *bufs_first,
+                           long long cs1, long long cn1, void *const *tables, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,6 +120,7 @@ struct fftw_plan_s {
        (steps [split, nsteps)) of chunk c on a second stream; each chunk works
        in scratch slot c % nslots */
     int nslots, split;
+    int pair;                   /* both passes of the 1024 x 1024 plan in one launch per chunk (fa_hip_launch_pair1024) */
     void *pstream[2];
     void *ev_a[4], *ev_b[4], *ev_begin, *ev_end[2];
     int failed;

@@ -14,6 +14,7 @@
  *   r2c_post / c2r_pre   <- ct_hc2c_direct_apply A.c:5831-5845 with the
  *       hc2cfdft / hc2cbdft codelets, plus the DC/Nyquist zeroing A.c:7155.
  */
+#include <string.h>
 #include "common.hpp"
 
 #include "pass1024.hpp"
@@ -981,11 +982,10 @@ static void launch_p1024_variant(const P1024Args &pa, dim3 grid, hipStream_t st)
     hipLaunchKernelGGL((pass1024_kernel<IN_T, OUT_T, HAS_TW>), grid, dim3(256), lds, st, pa);
 }
 
-/* the register-resident 1024-point pass; returns 1 if the step does not
-   qualify (caller falls through to the generic kernel) */
-static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
-                        i64 cs, i64 cn, hipStream_t st) {
-    P1024Args pa;
+/* arguments of the register-resident 1024-point pass for one step and chunk; returns 1 if the step
+   does not qualify (caller falls through to the generic kernel), 0 and *nblocks_out == 0 for an empty launch */
+static int fill_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                      i64 cs, i64 cn, P1024Args &pa, i64 *nblocks_out, bool *in_t, bool *out_t, int *tw) {
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
     if (d->L != 1024 || d->src_im != 1 || d->dst_im != 1 ||
@@ -1025,12 +1025,23 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
     pa.ntiles = (pa.dn[0] + (8 >> pa.lo_sh) - 1) / (8 >> pa.lo_sh);
     i64 nblocks = pa.ntiles;
     for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
-    if (nblocks <= 0) return 0;
     if (nblocks > 0x7fffffffLL) return 1;
+    *nblocks_out = nblocks < 0 ? 0 : nblocks;
+    *in_t = pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l);
+    *out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);
+    *tw = d->tw_n == 0 ? 0 : ((d->flags & FFTW_AMD_F_TW_IN) ? 2 : 1);
+    return 0;
+}
+
+static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                        i64 cs, i64 cn, hipStream_t st) {
+    P1024Args pa;
+    i64 nblocks = 0;
+    bool in_t, out_t;
+    int tw;
+    if (fill_p1024(d, bufs, tables, cs, cn, pa, &nblocks, &in_t, &out_t, &tw)) return 1;
+    if (nblocks <= 0) return 0;
     dim3 grid((unsigned)nblocks, 1, 1);
-    bool in_t = pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l);
-    bool out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);
-    int tw = d->tw_n == 0 ? 0 : ((d->flags & FFTW_AMD_F_TW_IN) ? 2 : 1);
 #define FA_P1024_CASE(I, O, W) if (in_t == I && out_t == O && tw == W) { launch_p1024_variant<I, O, W>(pa, grid, st); return 0; }
     FA_P1024_CASE(true, true, 0)  FA_P1024_CASE(true, true, 1)  FA_P1024_CASE(true, true, 2)
     FA_P1024_CASE(false, true, 0) FA_P1024_CASE(false, true, 1) FA_P1024_CASE(false, true, 2)
@@ -1038,6 +1049,80 @@ static int launch_p1024(const fftw_amd_step_desc *d, double *const *bufs, void *
     FA_P1024_CASE(false, false, 0) FA_P1024_CASE(false, false, 1) FA_P1024_CASE(false, false, 2)
 #undef FA_P1024_CASE
     return 1;
+}
+
+/* one tile of a launch described by `a`, block id `b0` of `nb` (XCD-contiguous order) */
+template <bool IN_T, bool OUT_T, int HAS_TW>
+FA_DEV void p1024_block(const P1024Args &a, unsigned b0, unsigned nb, double *plane) {
+    unsigned blk = (nb & 7) ? b0 : (b0 & 7) * (nb >> 3) + (b0 >> 3);
+    const unsigned nt = (unsigned)a.ntiles;
+    unsigned rest = blk / nt;
+    const unsigned tile = blk - rest * nt;
+    i64 soff = 0, doff = 0, twb = 0;
+    for (int d = 1; d < a.ndims; ++d) {
+        const unsigned dn = (unsigned)a.dn[d];
+        const unsigned q = rest / dn, idx = rest - q * dn;
+        rest = q;
+        soff += (i64)idx * a.dis[d];
+        doff += (i64)idx * a.dos[d];
+        twb += (i64)idx * a.dtw[d];
+    }
+    const i64 t0 = (i64)tile * 8;
+    P1024Tile t;
+    t.lo_sh = 0; t.lo_is = 0; t.lo_os = 0;
+    t.src = a.src + soff + t0 * a.dis[0];
+    t.dst = a.dst + doff + t0 * a.dos[0];
+    t.is_l = a.is_l; t.os_l = a.os_l;
+    t.dis0 = a.dis[0]; t.dos0 = a.dos[0];
+    t.dtw0 = a.dtw[0]; t.q0 = twb + t0 * a.dtw[0];
+    t.w1024 = a.w1024; t.tw_lo = a.tw_lo; t.tw_hi = a.tw_hi; t.tw_shift = a.tw_shift;
+    t.Tcur = (int)((a.dn[0] - t0 < 8) ? (a.dn[0] - t0) : 8);
+    t.flags = a.flags;
+    t.dbg = NULL;
+    p1024_tile<IN_T, OUT_T, HAS_TW, 0>(t, plane, threadIdx.x);
+}
+
+/* blocks [0, n2): row pass with input twiddle (pass 2 of the previous chunk); blocks [n2, n2 + n1):
+   column pass (pass 1 of this chunk).  See fa_hip_launch_pair1024. */
+__global__ void __launch_bounds__(256, 2)
+pass1024_pair_kernel(const P1024Args a2, const P1024Args a1, const unsigned n2, const unsigned n1) {
+    extern __shared__ __attribute__((aligned(16))) double plane[];
+    if (blockIdx.x < n2) p1024_block<false, true, 2>(a2, blockIdx.x, n2, plane);
+    else p1024_block<true, true, 0>(a1, blockIdx.x - n2, n1, plane);
+}
+
+/* The two passes of the batched N = 1024 x 1024 plan in ONE launch per chunk: first the tiles of
+   pass 2 of the previous chunk, then the tiles of pass 1 of this chunk (pass1024.hpp,
+   pass1024_pair_kernel).  Workgroups are dispatched in order, so pass 1 of chunk c fills the slots
+   that the tail of pass 2 of chunk c-1 leaves idle: one dependent launch boundary per chunk instead
+   of two.  Either half may be empty (first / last launch).  Returns 1 when the steps are not the
+   (column pass without twiddle, row pass with input twiddle) pair the kernel is built for. */
+extern "C" int fa_hip_launch_pair1024(const fftw_amd_step_desc *d_second, double *const *bufs_second,
+                                      long long cs2, long long cn2,
+                                      const fftw_amd_step_desc *d_first, double *const *bufs_first,
+                                      long long cs1, long long cn1, void *const *tables, void *stream) {
+    P1024Args a2, a1;
+    i64 n2 = 0, n1 = 0;
+    bool i2 = false, o2 = true, i1 = true, o1 = true;
+    int w2 = 2, w1 = 0;
+    memset((void *)&a2, 0, sizeof(a2));
+    memset((void *)&a1, 0, sizeof(a1));
+    if (cn2 > 0 && fill_p1024(d_second, bufs_second, tables, cs2, cn2, a2, &n2, &i2, &o2, &w2)) return 1;
+    if (cn1 > 0 && fill_p1024(d_first, bufs_first, tables, cs1, cn1, a1, &n1, &i1, &o1, &w1)) return 1;
+    if ((cn2 > 0 && (i2 || !o2 || w2 != 2 || a2.lo_sh)) || (cn1 > 0 && (!i1 || !o1 || w1 != 0 || a1.lo_sh))) return 1;
+    if (n1 + n2 <= 0) return 0;
+    if (n1 + n2 > 0x7fffffffLL) return 1;
+    static std::atomic<unsigned> attr_done{0};
+    const size_t lds = FA_P1024_LDS_DOUBLES * sizeof(double);
+    if (fa_attr_needed(attr_done)) {
+        FA_CHECK(hipFuncSetAttribute((const void *)pass1024_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        fa_attr_set(attr_done);
+    }
+    hipLaunchKernelGGL(pass1024_pair_kernel, dim3((unsigned)(n1 + n2)), dim3(256), lds, (hipStream_t)stream,
+                       a2, a1, (unsigned)n2, (unsigned)n1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fprintf(stderr, "fftw3_amd: pair launch failed: %s\n", hipGetErrorString(e)); return -1; }
+    return 0;
 }
 
 static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,

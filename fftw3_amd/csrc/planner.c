@@ -1900,7 +1900,24 @@ int fa_device_init(plan *p) {
     }
     /* chunk pipeline: worth it when there are several chunks of >= 2 steps */
     p->nslots = 1;
-    if (p->chunk > 0 && p->nsteps >= 2 && (p->batch + p->chunk - 1) / p->chunk >= 3 &&
+    p->pair = 0;
+    {
+        /* batched 1024 x 1024: pass 2 of chunk c-1 and pass 1 of chunk c share a launch (two scratch slots) */
+        static int pair_mode = -1;     /* FFTW_AMD_PAIR=0 switches it off */
+        if (pair_mode < 0) { const char *e = getenv("FFTW_AMD_PAIR"); pair_mode = e ? atoi(e) : 1; }
+        if (pair_mode && !p->cfg.pipeline && p->nsteps == 2 && p->nbufs == 3 && p->chunk > 0 && p->chunk < p->batch &&
+            !p->single_chunk &&
+            p->steps[0].kind == FFTW_AMD_STEP_PASS && p->steps[1].kind == FFTW_AMD_STEP_PASS &&
+            p->steps[0].variant == FFTW_AMD_K_P1024 && p->steps[1].variant == FFTW_AMD_K_P1024 &&
+            p->steps[0].src_buf == 0 && p->steps[0].dst_buf == 2 && p->steps[1].src_buf == 2 && p->steps[1].dst_buf == 1 &&
+            p->steps[0].tw_n == 0 && p->steps[1].tw_n != 0 && (p->steps[1].flags & FFTW_AMD_F_TW_IN) &&
+            p->steps[0].tile_lo_n <= 1 && p->steps[1].tile_lo_n <= 1 &&
+            p->steps[0].batch_dim >= 0 && p->steps[1].batch_dim >= 0) {
+            p->pair = 1;
+            p->nslots = 2;
+        }
+    }
+    if (!p->pair && p->chunk > 0 && p->nsteps >= 2 && (p->batch + p->chunk - 1) / p->chunk >= 3 &&
         !p->single_chunk && p->cfg.pipeline) {
         i64 per = 0;
         for (i = 2; i < p->nbufs; ++i) per += p->buf_reals[i];
@@ -2059,10 +2076,43 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
     for (i = 2; i < p->nbufs; ++i) bufs[i] = p->dbuf[i];
     for (i = 0; i < p->ntabs; ++i) tabs[i] = p->tabs[i].dev;
 
-    {
+    if (p->pair) {
+        /* launch k: pass 2 of chunk k-1 (scratch slot (k-1) & 1) + pass 1 of chunk k (slot k & 1) */
+        const i64 nchunks = (p->batch + p->chunk - 1) / p->chunk;
+        i64 k;
+        int ok = 1;
+        for (k = 0; k <= nchunks && ok; ++k) {
+            double *sb1[FA_MAXBUF], *sb2[FA_MAXBUF];
+            fftw_amd_step_desc d1 = p->steps[0], d2 = p->steps[1];
+            const i64 cs1 = k * p->chunk, cs2 = (k - 1) * p->chunk;
+            const i64 cn1 = k < nchunks ? (p->batch - cs1 < p->chunk ? p->batch - cs1 : p->chunk) : 0;
+            const i64 cn2 = k > 0 ? (p->batch - cs2 < p->chunk ? p->batch - cs2 : p->chunk) : 0;
+            void *e0 = NULL, *e1 = NULL;
+            sb1[0] = sb2[0] = bufs[0];
+            sb1[1] = sb2[1] = bufs[1];
+            sb1[2] = bufs[2] + (i64)(k & 1) * p->buf_reals[2];
+            sb2[2] = bufs[2] + (i64)((k + 1) & 1) * p->buf_reals[2];
+            if (d1.src_im == p->in_im && !FA_REAL_IN(p->type)) d1.src_im = in_im;
+            if (d2.dst_im == p->out_im && !FA_REAL_OUT(p->type)) d2.dst_im = out_im;
+            if (p->prof_ms) { e0 = fa_hip_event_create(); e1 = fa_hip_event_create(); fa_hip_event_record(e0, p->stream); }
+            if (fa_hip_launch_pair1024(&d2, sb2, cs2, cn2, &d1, sb1, cs1, cn1, tabs, p->stream)) {
+                if (k == 0) { ok = 0; }          /* not the pair the kernel is built for: ordinary launches below */
+                else abort();
+            }
+            if (p->prof_ms) {
+                fa_hip_event_record(e1, p->stream);
+                fa_hip_stream_sync(p->stream);
+                if (ok) { p->prof_ms[0] += (double)fa_hip_event_elapsed_ms(e0, e1); p->prof_launches[0] += 1; }
+                fa_hip_event_destroy(e0);
+                fa_hip_event_destroy(e1);
+            }
+        }
+        if (!ok) p->pair = 0;
+    }
+    if (!p->pair) {
         i64 nchunks = (p->batch + p->chunk - 1) / p->chunk, ev = 0, c = 0;
         void **events = NULL;
-        const int pipe = p->nslots > 1;
+        const int pipe = p->nslots > 1 && p->pstream[0];
         if (p->prof_ms) events = (void **)malloc(sizeof(void *) * (size_t)(2 * nchunks * p->nsteps));
         if (pipe) {
             /* the side streams start after everything already queued on the caller's stream */

@@ -205,6 +205,10 @@ int fftw_amd_plan_get_step(const fftw_plan p, int i, fftw_amd_step_desc *out);
 /* how many batch elements one chunk processes, and the total batch */
 long long fftw_amd_plan_chunk(const fftw_plan p);
 long long fftw_amd_plan_batch(const fftw_plan p);
+/* 1 when the executor runs both passes of a two-pass plan in one launch per chunk (pass 2 of chunk
+   c-1 followed by pass 1 of chunk c); fftw_amd_execute_profiled then reports every launch under step 0.
+   Known once the plan has been set up on a device. */
+int fftw_amd_plan_paired(const fftw_plan p);
 /* host copy of table `id` as interleaved doubles; returns its length in
    doubles (writes at most cap doubles). */
 long long fftw_amd_plan_table(const fftw_plan p, int id, double *dst, long long cap);

@@ -815,3 +815,43 @@ def test_unaligned_flag_and_new_array_execute_on_8_byte_offset(torch_dev):
     torch.cuda.synchronize()
     got = xout.cpu().numpy().view(np.complex128).reshape(b, n // 2 + 1)
     assert aerror(got, oracle_r2c(xr, (n,), b).reshape(b, n // 2 + 1)) < TOL
+
+
+def test_pair_launches_of_the_two_pass_plan(torch_dev):
+    """batched N = 1024 x 1024 with more than one chunk: pass 2 of chunk c-1 and pass 1 of chunk c share
+    a launch (fa_hip_launch_pair1024, two scratch slots).  Ragged last chunk, both signs, in place,
+    new-array execute -- all against the oracle."""
+    torch, dev = torch_dev
+    rng = np.random.default_rng(2020)
+    n, b = 1 << 20, 5
+    fa.set_chunk_bytes(32 << 20)                 # 2 transforms per chunk -> chunks of 2, 2, 1
+    try:
+        x = crand(rng, b, n)
+        xd = torch.from_numpy(x).to(dev)
+        for sign in (-1, 1):
+            yd = torch.zeros_like(xd)
+            p = fa.plan_many_dft(1, [n], b, xd, None, 1, n, yd, None, 1, n, sign)
+            assert p.chunk == 2 and p.batch == 5
+            p.execute()
+            torch.cuda.synchronize()
+            assert p.paired, "the pair launch did not engage"
+            assert aerror(yd.cpu().numpy(), oracle_dft(x, (n,), b, sign).reshape(b, n)) < TOL
+            # profiled execution reports every launch under step 0: chunks + 1 launches
+            prof = p.execute_profiled()
+            assert prof[0][2] == 4 and prof[1][2] == 0
+            torch.cuda.synchronize()
+            assert aerror(yd.cpu().numpy(), oracle_dft(x, (n,), b, sign).reshape(b, n)) < TOL
+        # in place + new-array execute on other buffers
+        zd = xd.clone()
+        q = fa.plan_many_dft(1, [n], b, zd, None, 1, n, zd, None, 1, n, fa.FORWARD)
+        q.execute()
+        torch.cuda.synchronize()
+        want = oracle_dft(x, (n,), b).reshape(b, n)
+        assert q.paired and aerror(zd.cpu().numpy(), want) < TOL
+        x2 = crand(rng, b, n)
+        z2 = torch.from_numpy(x2).to(dev)
+        q.execute_dft(z2, z2)
+        torch.cuda.synchronize()
+        assert aerror(z2.cpu().numpy(), oracle_dft(x2, (n,), b).reshape(b, n)) < TOL
+    finally:
+        fa.set_chunk_bytes(0)
