@@ -356,4 +356,60 @@ template <int A> struct BflySquare {
 template <> struct Bfly<9> : BflySquare<3> {};
 template <> struct Bfly<25> : BflySquare<5> {};
 
+
+/* radix 27 = 3 x 9 Cooley-Tukey (input j = i + 3 j2, output k = k2 + 9 k1), constants w27^(i k2) */
+template <> struct CtTw<27> {
+    static FA_DEV cplx w(int k) {
+        switch (k) {
+        case 1: return c_make(0.9730448705798238388328851727846959200349, 0.2306158707424401784501983492929391024576);
+        case 2: return c_make(0.8936326403234122481925741868666551173761, 0.4487991802004621727850403347331436164243);
+        case 3: return c_make(0.7660444431189780352023926505554166739358, 0.6427876096865393263226434099072634329076);
+        case 4: return c_make(0.5971585917027861648518521605839597728407, 0.8021231927550437850832948919339251336279);
+        case 5: return c_make(0.3960797660391568236960433916097445675085, 0.9182161068802740147589614153146366024814);
+        case 6: return c_make(0.1736481776669303488517166267693147960004, 0.9848077530122080593667430245895230136706);
+        case 7: return c_make(-0.05814482891047582853874801684707152363411, 0.9983081582712682080478207087832775329371);
+        case 8: return c_make(-0.2868032327110902531032801731671579370202, 0.957989512315488874437374766956754624258);
+        case 10: return c_make(-0.6862416378687335857296049996175379830146, 0.7273736415730486959871764176638155218004);
+        case 12: return c_make(-0.9396926207859083840541092773247314699362, 0.3420201433256687330440996146822595807631);
+        case 14: return c_make(-0.9932383577419429885478955521937043403491, -0.1160929141252302296756665233807114688535);
+        case 16: return c_make(-0.835487811412936419653826170019583593742, -0.5495089780708060352627803740501339165127);
+        default: return c_make(1.0, 0.0);
+        }
+    }
+};
+template <int A, int B> struct BflyCT {
+    static constexpr int N = A * B;
+    static FA_DEV void run(cplx *x) {
+        cplx z[A][B];
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+#pragma unroll
+            for (int j = 0; j < B; ++j) z[i][j] = x[i + A * j];
+            Bfly<B>::run(z[i]);
+        }
+#pragma unroll
+        for (int i = 1; i < A; ++i)
+#pragma unroll
+            for (int k2 = 1; k2 < B; ++k2) z[i][k2] = c_mulc(z[i][k2], CtTw<N>::w(i * k2));
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) {
+            cplx c[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) c[i] = z[i][k2];
+            Bfly<A>::run(c);
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) x[k2 + B * k1] = c[k1];
+        }
+    }
+};
+template <> struct Bfly<27> : BflyCT<3, 9> {};
+/* more coprime products (prime-factor maps, no twiddles): the reference has n1_/t1_ codelets up to 64
+   for powers of two only; these fill the register-kernel menu for 7-smooth lengths */
+template <> struct Bfly<18> : BflyPFA<2, 9> {};
+template <> struct Bfly<21> : BflyPFA<3, 7> {};
+template <> struct Bfly<22> : BflyPFA<2, 11> {};
+template <> struct Bfly<26> : BflyPFA<2, 13> {};
+template <> struct Bfly<28> : BflyPFA<4, 7> {};
+template <> struct Bfly<30> : BflyPFA<2, 15> {};
+
 #endif /* FA_BUTTERFLIES_H */

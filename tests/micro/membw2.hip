@@ -194,6 +194,12 @@ int main(int argc, char **argv) {
         TP(EPT, WGPC, false, 0, true, 0, 32, "contig -> seg32"); \
         TP(EPT, WGPC, false, 0, true, 4, 4, "seg4 -> seg4"); \
         TP(EPT, WGPC, false, 0, false, 8, 8, "seg8 -> seg8 no barrier"); \
+        TP(EPT, WGPC, false, 1, true, 4, 4, "seg4 -> seg4"); \
+        TP(EPT, WGPC, true, 1, true, 4, 4, "seg4 -> seg4"); \
+        TP(EPT, WGPC, true, 1, true, 4, 8, "seg4 -> seg8"); \
+        TP(EPT, WGPC, true, 1, true, 0, 4, "contig -> seg4"); \
+        TP(EPT, WGPC, true, 1, true, 2, 2, "seg2 -> seg2"); \
+        TP(EPT, WGPC, true, 1, true, 0, 2, "contig -> seg2"); \
         } while (0)
         TPSET(32, 2); TPSET(16, 4); TPSET(8, 8); TPSET(16, 2); TPSET(32, 1);
     }

@@ -29,6 +29,9 @@ extern "C" int bfly(int r, double *d) {
     case 15: run<15>(d); break; case 6: run<6>(d); break; case 9: run<9>(d); break;
     case 10: run<10>(d); break; case 12: run<12>(d); break; case 14: run<14>(d); break;
     case 20: run<20>(d); break; case 24: run<24>(d); break; case 25: run<25>(d); break;
+    case 18: run<18>(d); break; case 21: run<21>(d); break; case 22: run<22>(d); break;
+    case 26: run<26>(d); break; case 27: run<27>(d); break; case 28: run<28>(d); break;
+    case 30: run<30>(d); break;
     default: return -1;
     }
     return 0;
@@ -41,12 +44,12 @@ def test_butterflies_match_dft():
         src = os.path.join(td, "b.cpp")
         so = os.path.join(td, "b.so")
         open(src, "w").write(SRC)
-        subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC",
+        subprocess.run(["g++", "-O0", "-std=c++17", "-shared", "-fPIC",
                         "-I", os.path.join(ROOT, "fftw3_amd", "csrc"), src, "-o", so], check=True)
         lib = C.CDLL(so)
         lib.bfly.argtypes = [C.c_int, C.c_void_p]
         rng = np.random.default_rng(0)
-        for r in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 20, 24, 25):
+        for r in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 21, 22, 24, 25, 26, 27, 28, 30):
             for _ in range(3):
                 x = rng.random(r) - 0.5 + 1j * (rng.random(r) - 0.5)
                 d = x.copy()

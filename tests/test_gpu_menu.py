@@ -72,11 +72,13 @@ def test_menu_is_complete_and_consistent():
 
 @pytest.mark.parametrize("L,r1,r2", MENU, ids=[str(m[0]) for m in MENU])
 def test_single_pass_rows_and_columns(L, r1, r2):
+    # contiguous rows of a length that also has a three-stage rows kernel (525 ... 648) may take that one
+    rows3 = any(m[0] == L for m in MENU3)
     p, e = _run(L, 300, 1, L)
-    assert "pass-%d/reg2" % L in p.sprint(), p.sprint()
+    assert "pass-%d/reg2" % L in p.sprint() or (rows3 and "pass-%d/reg3" % L in p.sprint()), p.sprint()
     assert e <= TOL, (L, e)
     p, e = _run(L, 300, 300, 1)
-    assert "pass-%d/reg2" % L in p.sprint(), p.sprint()
+    assert "pass-%d/reg2" % L in p.sprint() or "pass-%d/reg3" % L in p.sprint(), p.sprint()
     assert e <= TOL, (L, e)
 
 
