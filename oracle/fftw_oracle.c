@@ -5,6 +5,10 @@
  * links or calls this file; it is the checker for tests/, for
  * __graft_entry__.smoke() and for bench.py's cpu_baseline leg.
  *
+ * PINNING STATUS: "parity unpinned" in the strict sense of the project rules -- no output of the
+ * reference library itself (neither a build of it nor vectors stored in its tree) anchors this
+ * file; what anchors it is listed below.
+ *
  * PINNING: the reference itself could not be built under the rules of this
  * project (fftw/fftw_api.h:57 includes a config.h that only the reference's
  * CMake configure step generates, and that build system may not be run), and
