@@ -146,6 +146,11 @@ int main() {
     V vs[] = { {"product kernel", launch_pair<0>}, {"persistent 2 WG/CU", launch_pair_persist}, {"no butterflies", launch_pair<1>}, {"no twiddles", launch_pair<2>},
                {"no LDS exchange", launch_pair<4>}, {"no bfly, no tw", launch_pair<3>}, {"memory + LDS only... (1|2)", launch_pair<3>},
                {"memory only (1|2|4)", launch_pair<7>} };
+    /* warm-up: the first variant timed in a process reads 3-4 % slow (clocks / page tables), which once made
+       every later variant look like an improvement */
+    for (int r = 0; r < 6; ++r)
+        for (int k = 0; k < NT / 16; ++k) launch_pair<0>(in + (i64)k * 16 * N * 2, scr, out + (i64)k * 16 * N * 2, 16, w, lo, hi, 1, st);
+    FA_CHECK(hipDeviceSynchronize());
     printf("%-28s %4s %3s | %9s %7s\n", "variant", "C", "nt", "us/xform", "whole%");
     for (int nt : {1}) for (int C : {16, 12, 20, 24, 32}) for (auto &v : vs) {
         if (C != 16 && v.f != (pairfn)launch_pair<0> && v.f != (pairfn)launch_pair_persist) continue;
