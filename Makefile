@@ -16,7 +16,13 @@ all: $(LIBDIR)/libfftw3_amd.so
 $(CSRC)/%.o: $(CSRC)/%.c $(CSRC)/fa_plan.h $(CSRC)/fa_hip.h $(CSRC)/split_costs.inc include/fftw3.h include/fftw3_amd.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_amd.h $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc)
+# every HIP unit depends on exactly the headers it includes (a full rebuild of the two menu units takes minutes)
+HIPCOMMON := $(CSRC)/common.hpp $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_amd.h $(CSRC)/pass1024.hpp
+$(CSRC)/kernels.o: $(CSRC)/kernels.hip $(HIPCOMMON) $(CSRC)/r2r_epi.hpp
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/kernels_rr.o: $(CSRC)/kernels_rr.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/rr_menu.inc
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/kernels_r3.o: $(CSRC)/kernels_r3.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass3g.hpp $(CSRC)/r2crows.hpp $(CSRC)/r2r_epi.hpp $(CSRC)/r3_menu.inc $(CSRC)/r3t_menu.inc
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libfftw3_amd.so: $(OBJS)

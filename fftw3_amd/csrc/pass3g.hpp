@@ -207,7 +207,7 @@ template <int R1, int R2, int R3> struct P3TGeom {
     static constexpr int T = 8192 / L;
     static constexpr int NBA = T * M, NBB = T * R1 * R3, NBC = T * R1 * R2;
     static constexpr int QA = fa_3g_q(NBA), QB = fa_3g_q(NBB), QC = fa_3g_q(NBC);
-    static constexpr bool fits = T >= 8 && QA * R1 <= 40 && QB * R2 <= 40 && QC * R3 <= 40;   /* the menu keeps only spill-free ones */
+    static constexpr bool fits = T >= 4 && QA * R1 <= 40 && QB * R2 <= 40 && QC * R3 <= 40;   /* the menu keeps only spill-free ones; T = 4 (64-byte segments) only for 2048 */
     static constexpr int TP = T + 1;                               /* odd stride of t where it is not fastest */
     /* column form: element (d1, a, t) at (d1 * M + a) * T + t, rows of d1 padded to stride = T mod 32 */
     static constexpr int S1C = M * T + ((32 + T - (M * T) % 32) % 32);

@@ -865,6 +865,13 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     }
     k = fa_factor_passes_pref(ax.n, FA_MAXPASS, lmax1, contiguous ? p->cfg.lmax_multi : FA_TILE_ELEMS / 8, lens,
                               getenv("FFTW_AMD_NO_TUNED") ? NULL : has_register_kernel);
+    /* 2^21 = 2048 x 1024 in TWO trips: the strided 2048-point three-stage kernel works on tiles of 4 columns
+       (64-byte segments, ~3.2 TB/s) -- slower per trip than the 128-byte kernels, but two trips beat three
+       (measured 7.9 vs 11.2 ms per 8 GiB; for 2^22 = 2048 x 2048 the two slow trips only tie with three fast ones) */
+    if (k == 3 && contiguous && ax.n == ((i64)1 << 21) && fa_hip_r3t_tile(2048) > 0 && ax.nloops > 0 &&
+        !getenv("FFTW_AMD_NO_TUNED")) {
+        k = 2; lens[0] = 2048; lens[1] = 1024;
+    }
     if (k == 3 && contiguous && (ax.n & (ax.n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) pow2_three_pass_split(ax.n, lens);
     else if (k == 3 && contiguous && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_SPLIT_COSTS")) mixed_three_pass_split(ax.n, lens);
     {

@@ -130,6 +130,22 @@ def test_three_stage_strided_forms(L, r1, r2, r3, monkeypatch):
     (T,T,0) single column pass and first pass of L x L, (L,T,2) its second pass,
     (T,T,1) x2 in a forced L x L x 8 split, (L,T,0) as the last pass of 64 x 8 x L"""
     assert r1 * r2 * r3 == L
+    if L > 1024:
+        # 4-wide tiles (64-byte segments): the planner uses this kernel for 2^21 = 2048 x 1024 only; reach
+        # the column form, the transposed-last form with input twiddle and the output-twiddle form by force
+        monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "%d,1024" % L)
+        p, e = _run(L * 1024, 2, 1, L * 1024)
+        assert "pass-%d/reg3" % L in p.sprint(), p.sprint()
+        assert e <= TOL, (L, e)
+        monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "1024,%d" % L)
+        p, e = _run(L * 1024, 2, 1, L * 1024)
+        assert "pass-%d/reg3" % L in p.sprint(), p.sprint()
+        assert e <= TOL, (L, e)
+        monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "%d,%d,8" % (L, 64))
+        p, e = _run(L * 512, 2, 1, L * 512)
+        assert "pass-%d/reg3" % L in p.sprint(), p.sprint()
+        assert e <= TOL, (L, e)
+        return
     p, e = _run(L, 300, 300, 1)                       # interleaved batch: one column pass
     assert "pass-%d/reg3" % L in p.sprint(), p.sprint()
     assert e <= TOL, (L, e)

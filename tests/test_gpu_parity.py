@@ -37,7 +37,7 @@ def gpu_c2c(torch_dev, x, shape, b, sign=-1, inplace=False):
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 16, 17, 25, 31, 32, 61, 64, 77,
                                97, 100, 143, 1009, 1024, 1031, 4096, 5000, 15015, 17408, 65536,
-                               65537, 1 << 20])
+                               65537, 1 << 20, 1 << 21])
 def test_c2c_1d_matches_oracle(torch_dev, n):
     rng = np.random.default_rng(n)
     for b in (1, 3):
