@@ -797,24 +797,52 @@ static double split_cost_of(i64 L, int pos) {
         if (g_split_costs[i].L == L && g_split_costs[i].c[pos] > 0.0) return g_split_costs[i].c[pos];
     return g_split_costs[n - 1].c[pos];
 }
-static void mixed_three_pass_split(i64 n, i64 *lens) {
-    i64 a, c;
-    double best = -1.0;
-    for (a = 16; a <= 1024; ++a) {
-        if (n % a || !has_register_kernel(a)) continue;
-        for (c = 16; c <= 1024; ++c) {
-            i64 m, lo, hi;
-            double cost;
-            if ((n / a) % c || !has_register_kernel(c)) continue;
-            m = n / a / c;
-            if (m < 16 || m > 1024 || !has_register_kernel(m)) continue;
-            lo = a < c ? a : c; if (m < lo) lo = m;
-            hi = a > c ? a : c; if (m > hi) hi = m;
-            if (hi > 4 * lo) continue;
-            cost = split_cost_of(a, 0) + split_cost_of(m, 1) + split_cost_of(c, 2);
-            if (best < 0.0 || cost < best) { best = cost; lens[0] = a; lens[1] = m; lens[2] = c; }
+/* the measured value only: 0 when the table has no sample for (L, pos) */
+static double split_cost_measured(i64 L, int pos) {
+    const int n = (int)(sizeof(g_split_costs) / sizeof(g_split_costs[0]));
+    int i;
+    for (i = 0; i < n - 1; ++i)
+        if (g_split_costs[i].L == L) return g_split_costs[i].c[pos];
+    return 0.0;
+}
+/* factor on the first (row 0) / last (row 1) pass by min(5, v2(stride)): their strided side moves runs of
+   T x 16 bytes that start at multiples of the stride, and runs that do not start on a 128-byte line cost up
+   to 1.3x (tools/perf/fit_split_costs.py) */
+static const double g_split_align[2][6] = {
+#include "split_align.inc"
+};
+static int v2_capped(i64 x) { int k = 0; while (k < 5 && (x & 1) == 0) { x >>= 1; ++k; } return k; }
+
+/* returns the modelled cost of the split it chose (ms per GiB of a pass, three passes), -1 if none.
+   Candidates whose FIRST length is a multiple of 8 come first: with an odd or barely even first length the
+   two later passes ran up to 1.3x slower than their lengths' medians in the sweeps (their loops over the first
+   pass's output index then start off the 128-byte grid); restricted to L1 % 8 == 0 the model's pick is within
+   4.3 % of the measured best on all ten lengths of the sweep, unrestricted it misses by up to 34 %. */
+static double mixed_three_pass_split(i64 n, i64 *lens) {
+    static const int need[4] = { 8, 4, 2, 1 };
+    int level;
+    for (level = 0; level < 4; ++level) {
+        i64 a, c;
+        double best = -1.0;
+        for (a = 16; a <= 1024; ++a) {
+            if (n % a || a % need[level] || !has_register_kernel(a)) continue;
+            for (c = 16; c <= 1024; ++c) {
+                i64 m, lo, hi;
+                double cost;
+                if ((n / a) % c || !has_register_kernel(c)) continue;
+                m = n / a / c;
+                if (m < 16 || m > 1024 || !has_register_kernel(m)) continue;
+                lo = a < c ? a : c; if (m < lo) lo = m;
+                hi = a > c ? a : c; if (m > hi) hi = m;
+                if (hi > 4 * lo) continue;
+                cost = split_cost_of(a, 0) * g_split_align[0][v2_capped(m * c)] + split_cost_of(m, 1) +
+                       split_cost_of(c, 2) * g_split_align[1][v2_capped(a * m)];
+                if (best < 0.0 || cost < best) { best = cost; lens[0] = a; lens[1] = m; lens[2] = c; }
+            }
         }
+        if (best >= 0.0) return best;
     }
+    return -1.0;
 }
 
 static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
@@ -837,6 +865,12 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     lmax1 = contiguous ? FA_LMAX_SINGLE : FA_TILE_ELEMS / 8;
     /* a strided axis with a register kernel of its own length needs no split either */
     if (!contiguous && ax.n <= 1024 && !getenv("FFTW_AMD_NO_TUNED") && has_register_kernel(ax.n)) lmax1 = 1024;
+    /* ... and neither does a strided axis of 1025 ... 2048 points with a narrow-tile three-stage kernel
+       (4 ... 7 sequences per tile, 64 ... 112-byte segments, ~3 TB/s): the 1080 of a 1080 x 1920 image */
+    if (!contiguous && ax.n > 1024 && ax.n <= 2048 && ax.nloops > 0 && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_NARROW") &&
+        fa_hip_r3t_tile((int)ax.n) > 0 && ax.src.im == 1 && ax.dst.im == 1 &&
+        !((ax.flags_in | ax.flags_out) & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT)))
+        lmax1 = 2048;
     /* powers of two above 1024 run faster as two register-kernel passes than
        as one LDS-sized pass (measured: 4096-point rows 0.8 TB/s vs ~5 TB/s per pass) */
     if (contiguous && ax.n > 1024 && (ax.n & (ax.n - 1)) == 0 && ax.nloops > 0 &&
@@ -865,12 +899,29 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     }
     k = fa_factor_passes_pref(ax.n, FA_MAXPASS, lmax1, contiguous ? p->cfg.lmax_multi : FA_TILE_ELEMS / 8, lens,
                               getenv("FFTW_AMD_NO_TUNED") ? NULL : has_register_kernel);
-    /* 2^21 = 2048 x 1024 in TWO trips: the strided 2048-point three-stage kernel works on tiles of 4 columns
-       (64-byte segments, ~3.2 TB/s) -- slower per trip than the 128-byte kernels, but two trips beat three
-       (measured 7.9 vs 11.2 ms per 8 GiB; for 2^22 = 2048 x 2048 the two slow trips only tie with three fast ones) */
-    if (k == 3 && contiguous && ax.n == ((i64)1 << 21) && fa_hip_r3t_tile(2048) > 0 && ax.nloops > 0 &&
-        !getenv("FFTW_AMD_NO_TUNED")) {
-        k = 2; lens[0] = 2048; lens[1] = 1024;
+    /* n = L1 x L2 with 1024 < L1 <= 2048 in TWO trips instead of three: the strided three-stage kernel of
+       such a length works on tiles of 4 ... 7 columns (64 ... 112-byte segments, ~3.2 TB/s) -- slower per trip
+       than the 128-byte kernels, but two trips beat three (2^21 = 2048 x 1024: 7.9 vs 11.2 ms per 8 GiB; with
+       BOTH lengths above 1024 the two slow trips only tie with three fast ones, so that is not done) */
+    if (k == 3 && contiguous && ax.nloops > 0 && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_NARROW")) {
+        /* cost per GiB of a pass (the units of split_costs.inc): narrow-tile first pass 0.34 (2048-point: 5.33 ms
+           per 16 GiB), the partner as LAST pass from the table (1024: 0.18, the cfg2 pass; 1000: 0.20); the
+           three-pass alternative from the same table (powers of two: 0.68, measured 2^21 ... 2^24) */
+        i64 L1, bestL1 = 0, l3[FA_MAXPASS];
+        double best2 = 1e30, est3 = 0.68;
+        if ((ax.n & (ax.n - 1)) != 0) {
+            double c3 = mixed_three_pass_split(ax.n, l3);
+            if (c3 > 0.0) est3 = c3;
+        }
+        for (L1 = 2048; L1 > 1024; --L1) {
+            i64 L2 = ax.n / L1;
+            double c2;
+            if (ax.n % L1 || fa_hip_r3t_tile((int)L1) <= 0 || L2 > 1024 || L2 < 96 || !has_register_kernel(L2)) continue;
+            c2 = L2 == 1024 ? 0.18 : (L2 == 1000 ? 0.20 : split_cost_measured(L2, 2));
+            if (c2 <= 0.0) continue;                  /* no measurement for that partner: do not guess */
+            if (0.34 + c2 < best2) { best2 = 0.34 + c2; bestL1 = L1; }
+        }
+        if (bestL1 && best2 < 0.95 * est3) { k = 2; lens[0] = bestL1; lens[1] = ax.n / bestL1; }
     }
     if (k == 3 && contiguous && (ax.n & (ax.n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) pow2_three_pass_split(ax.n, lens);
     else if (k == 3 && contiguous && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_SPLIT_COSTS")) mixed_three_pass_split(ax.n, lens);
