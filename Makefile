@@ -13,7 +13,7 @@ OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/sharded.o $(CSRC)/hostmath.o $(C
 
 all: $(LIBDIR)/libfftw3_amd.so
 
-$(CSRC)/%.o: $(CSRC)/%.c $(CSRC)/fa_plan.h $(CSRC)/fa_hip.h $(CSRC)/split_costs.inc $(CSRC)/split_align.inc include/fftw3.h include/fftw3_amd.h
+$(CSRC)/%.o: $(CSRC)/%.c $(CSRC)/fa_plan.h $(CSRC)/fa_hip.h $(CSRC)/split_costs.inc $(CSRC)/split_align.inc $(CSRC)/split2_costs.inc $(CSRC)/split2_align.inc include/fftw3.h include/fftw3_amd.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
 # every HIP unit depends on exactly the headers it includes (a full rebuild of the two menu units takes minutes)

@@ -845,6 +845,45 @@ static double mixed_three_pass_split(i64 n, i64 *lens) {
     return -1.0;
 }
 
+/* Two-pass split n = L1 x L2 by the measured model of tools/perf/fit_split_costs.py (split2_costs.inc: median cost of
+   every menu length as first / last pass over 919 timed plans of 78 lengths; split2_align.inc: the price of strided
+   runs that start off the 128-byte grid, which depends on the OTHER length's factors of two and on the tile width T:
+   cost = c * (1 + 8 / T * m[v2(other)])).  Against the measured best split: mean +0.8 %, worst +9.8 %; the balanced
+   split it replaces: mean +9.6 %, worst +43 % (65 536 = 128 x 512 instead of 256 x 256: 2.67 vs 3.07 ms per 4 GiB). */
+static const split_cost g_split2_costs[] = {
+#include "split2_costs.inc"
+};
+static const double g_split2_align[2][6] = {
+#include "split2_align.inc"
+};
+static double split2_cost_of(i64 L, int pos) {
+    const int n = (int)(sizeof(g_split2_costs) / sizeof(g_split2_costs[0]));
+    int i;
+    for (i = 0; i < n - 1; ++i)
+        if (g_split2_costs[i].L == L && g_split2_costs[i].c[pos] > 0.0) return g_split2_costs[i].c[pos];
+    return g_split2_costs[n - 1].c[pos];
+}
+static int split_tile_of(i64 L) {
+    int t = L == 1024 ? 8 : fa_hip_rr_tile((int)L);
+    if (t <= 0) t = fa_hip_r3t_tile((int)L);
+    return t > 0 ? t : 8;
+}
+static void mixed_two_pass_split(i64 n, i64 *lens) {
+    i64 a;
+    double best = -1.0;
+    for (a = 16; a <= 1024; ++a) {
+        i64 b;
+        double cost;
+        if (n % a || !has_register_kernel(a)) continue;
+        b = n / a;
+        if (b < 16 || b > 1024 || !has_register_kernel(b)) continue;
+        if (a > 8 * b || b > 8 * a) continue;
+        cost = split2_cost_of(a, 0) * (1.0 + 8.0 / split_tile_of(a) * g_split2_align[0][v2_capped(b)]) +
+               split2_cost_of(b, 1) * (1.0 + 8.0 / split_tile_of(b) * g_split2_align[1][v2_capped(a)]);
+        if (best < 0.0 || cost < best) { best = cost; lens[0] = a; lens[1] = b; }
+    }
+}
+
 static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     fa_axis ax = *ax_in;
     i64 lens[FA_MAXPASS];
@@ -925,6 +964,8 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     }
     if (k == 3 && contiguous && (ax.n & (ax.n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) pow2_three_pass_split(ax.n, lens);
     else if (k == 3 && contiguous && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_SPLIT_COSTS")) mixed_three_pass_split(ax.n, lens);
+    else if (k == 2 && contiguous && ax.nloops > 0 && lens[0] <= 1024 && lens[1] <= 1024 && !getenv("FFTW_AMD_NO_TUNED") &&
+             !getenv("FFTW_AMD_NO_SPLIT_COSTS")) mixed_two_pass_split(ax.n, lens);
     {
         /* test hook: FFTW_AMD_FORCE_LENS="L1,L2,..." fixes the split of the axis whose length
            is the product (tests/test_gpu_menu.py reaches every kernel variant with it) */

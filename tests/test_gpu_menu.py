@@ -83,7 +83,9 @@ def test_single_pass_rows_and_columns(L, r1, r2):
 
 
 @pytest.mark.parametrize("L,r1,r2", MENU, ids=[str(m[0]) for m in MENU])
-def test_two_pass_square(L, r1, r2):
+def test_two_pass_square(L, r1, r2, monkeypatch):
+    # the planner's cost model may prefer another split of L * L: this test is about the kernel of length L
+    monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "%d,%d" % (L, L))
     p, e = _run(L * L, 3, 1, L * L)
     s = p.sprint()
     assert s.count("pass-%d/reg2" % L) == 2 or L * L <= 4096, s
@@ -149,6 +151,7 @@ def test_three_stage_strided_forms(L, r1, r2, r3, monkeypatch):
     p, e = _run(L, 300, 300, 1)                       # interleaved batch: one column pass
     assert "pass-%d/reg3" % L in p.sprint(), p.sprint()
     assert e <= TOL, (L, e)
+    monkeypatch.setenv("FFTW_AMD_FORCE_LENS", "%d,%d" % (L, L))
     p, e = _run(L * L, 3, 1, L * L)
     assert p.sprint().count("pass-%d/reg3" % L) == 2, p.sprint()
     assert e <= TOL, (L, e)
