@@ -7,8 +7,8 @@ O=$R/gpurun_out/prof_r02
 rm -rf $O; mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-legs --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 tools/perf/perf_traffic.py > $O/fetch.out 2> $O/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/perf/perf_traffic.py > $O/write.out 2> $O/write.err
+FFTW_AMD_PAIR=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 tools/perf/perf_traffic.py > $O/fetch.out 2> $O/fetch.err
+FFTW_AMD_PAIR=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/perf/perf_traffic.py > $O/write.out 2> $O/write.err
 find $O -name "*.csv" | head -20
 F=$(find $O/fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/write -name "*counter_collection.csv" | head -1)
