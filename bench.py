@@ -467,13 +467,26 @@ def main():
         # FFTW_AMD_BENCH_REHEARSE=1: rehearsal of the multi-rank path on a box with fewer GPUs
         # than ranks (ranks share cuda:0, gloo in the place of RCCL); never used for numbers
         rehearse = os.environ.get("FFTW_AMD_BENCH_REHEARSE") == "1"
-        if rehearse:
-            local_rank = local_rank % torch.cuda.device_count()
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # the collective libraries announce themselves on fd 1 while they initialise ("[Gloo] Rank 0 is
+        # connected ...", RCCL's "Hostname / Librccl path" banner): send fd 1 to stderr for that long, so that
+        # the ONE JSON line stays alone on stdout whichever launcher started this rank
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearse:
+                local_rank = local_rank % torch.cuda.device_count()
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("gloo")
+            else:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()                  # communicators are really built on first use
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
