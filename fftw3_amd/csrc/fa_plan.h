@@ -125,7 +125,8 @@ struct fftw_plan_s {
     void *ev_a[4], *ev_b[4], *ev_begin, *ev_end[2];
     int failed;
 
-    /* staging for plain host pointers */
+    /* staging for plain host pointers; hstream[0] / [1]: copy streams of the chunked host pipeline */
+    void *hstream[2];
     double *stage_in, *stage_out;
     size_t stage_in_bytes, stage_out_bytes;
 

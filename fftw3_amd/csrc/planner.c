@@ -98,6 +98,8 @@ void fa_plan_free(plan *p) {
         for (i = 2; i < p->nbufs; ++i) fa_hip_free(p->dbuf[i]);
         fa_hip_free(p->stage_in);
         fa_hip_free(p->stage_out);
+        if (p->hstream[0]) fa_hip_stream_destroy(p->hstream[0]);
+        if (p->hstream[1]) fa_hip_stream_destroy(p->hstream[1]);
         if (p->pstream[0]) {
             for (i = 0; i < 4; ++i) { fa_hip_event_destroy(p->ev_a[i]); fa_hip_event_destroy(p->ev_b[i]); }
             fa_hip_event_destroy(p->ev_begin);
@@ -2112,8 +2114,9 @@ void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
 static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *io) {
     double *bufs[FA_MAXBUF];
     void *tabs[FA_MAXTAB];
-    int i, in_host = 0, out_host = 0, host_inplace = 0;
-    i64 cs;
+    int i, in_host = 0, out_host = 0, host_inplace = 0, hpipe = 0;
+    i64 cs, nhchunks = 0, hp_ibs = 0, hp_obs = 0, hp_ispan = 0, hp_ospan = 0;
+    void **ev_in = NULL, **ev_out = NULL;
     i64 in_im = ii - ri, out_im = io - ro, out_im_host = 0;
     stage_layout Lin, Lout;
     double *din = ri, *dout = ro;
@@ -2150,10 +2153,47 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
             Lout.lo = Lin.lo; Lout.hi = Lin.hi; Lout.span = Lin.span;
         }
     }
+    /* Host pipeline: a batch that is dense on both sides (every transform's span below the batch stride) and
+       runs in several chunks is staged chunk by chunk on two copy streams -- upload of chunk c+1, compute of
+       chunk c and download of chunk c-1 overlap, so an unmodified host caller sees max(H2D, D2H) of the PCIe
+       link instead of their sum plus the compute.  Everything else is staged whole, as before. */
+    if (in_host && out_host && !host_inplace && !Lin.two && !Lout.two && p->hrank == 1 && !p->prof_ms &&
+        p->chunk > 0 && p->chunk < p->batch && !p->single_chunk && !(p->nslots > 1 && p->pstream[0])) {
+        const i64 B = p->batch, ibs = p->hdims[0].is, obs = p->hdims[0].os;
+        const i64 it_span = Lin.span - (B - 1) * ibs, ot_span = Lout.span - (B - 1) * obs;   /* one transform's span */
+        static int hp_mode = -1;        /* FFTW_AMD_HOST_PIPELINE=0 switches it off */
+        if (hp_mode < 0) { const char *e = getenv("FFTW_AMD_HOST_PIPELINE"); hp_mode = e ? atoi(e) : 1; }
+        if (hp_mode && ibs > 0 && obs > 0 && it_span > 0 && ot_span > 0 && it_span <= ibs && ot_span <= obs &&
+            Lout.span == p->out_written) {
+            hpipe = 1;
+            hp_ibs = ibs; hp_obs = obs; hp_ispan = it_span; hp_ospan = ot_span;
+            nhchunks = (B + p->chunk - 1) / p->chunk;
+            if (!p->hstream[0]) { p->hstream[0] = fa_hip_stream_create(); p->hstream[1] = fa_hip_stream_create(); }
+            ev_in = (void **)calloc((size_t)nhchunks, sizeof(void *));
+            ev_out = (void **)calloc((size_t)nhchunks, sizeof(void *));
+        }
+    }
     if (in_host) {
         double *st = stage_buf(&p->stage_in, &p->stage_in_bytes, stage_bytes(&Lin));
-        stage_h2d(&Lin, st, ri, in_im, p->stream);
         din = stage_origin(&Lin, st);
+        if (hpipe) {
+            /* uploads are queued now, in chunk order, behind whatever the caller's stream already holds */
+            i64 c;
+            void *e0 = fa_hip_event_create();
+            fa_hip_event_record(e0, p->stream);
+            fa_hip_stream_wait_event(p->hstream[0], e0);
+            fa_hip_stream_wait_event(p->hstream[1], e0);
+            fa_hip_event_destroy(e0);
+            for (c = 0; c < nhchunks; ++c) {
+                const i64 c0 = c * p->chunk, cn = (p->batch - c0 < p->chunk) ? p->batch - c0 : p->chunk;
+                const i64 lo = Lin.lo + c0 * hp_ibs, len = (cn - 1) * hp_ibs + hp_ispan;
+                fa_hip_memcpy_h2d(din + lo, ri + lo, (size_t)len * sizeof(double), p->hstream[0]);
+                ev_in[c] = fa_hip_event_create();
+                fa_hip_event_record(ev_in[c], p->hstream[0]);
+            }
+        } else {
+            stage_h2d(&Lin, st, ri, in_im, p->stream);
+        }
         in_im = Lin.im_dev;
     }
     if (out_host) {
@@ -2194,9 +2234,18 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
             if (d1.src_im == p->in_im && !FA_REAL_IN(p->type)) d1.src_im = in_im;
             if (d2.dst_im == p->out_im && !FA_REAL_OUT(p->type)) d2.dst_im = out_im;
             if (p->prof_ms) { e0 = fa_hip_event_create(); e1 = fa_hip_event_create(); fa_hip_event_record(e0, p->stream); }
+            if (hpipe && k < nchunks) fa_hip_stream_wait_event(p->stream, ev_in[k]);     /* chunk k is on the device */
             if (fa_hip_launch_pair1024(&d2, sb2, cs2, cn2, &d1, sb1, cs1, cn1, tabs, p->stream)) {
                 if (k == 0) { ok = 0; }          /* not the pair the kernel is built for: ordinary launches below */
                 else abort();
+            }
+            if (hpipe && ok && k > 0) {
+                /* chunk k-1 is complete: download it while the next launches run */
+                const i64 lo = Lout.lo + cs2 * hp_obs, len = (cn2 - 1) * hp_obs + hp_ospan;
+                ev_out[k - 1] = fa_hip_event_create();
+                fa_hip_event_record(ev_out[k - 1], p->stream);
+                fa_hip_stream_wait_event(p->hstream[1], ev_out[k - 1]);
+                fa_hip_memcpy_d2h(ro + lo, dout + lo, (size_t)len * sizeof(double), p->hstream[1]);
             }
             if (p->prof_ms) {
                 fa_hip_event_record(e1, p->stream);
@@ -2226,6 +2275,7 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
             sb[0] = bufs[0];
             sb[1] = bufs[1];
             for (i = 2; i < p->nbufs; ++i) sb[i] = bufs[i] + (i64)slot * p->buf_reals[i];
+            if (hpipe) fa_hip_stream_wait_event(p->stream, ev_in[c]);
             for (i = 0; i < p->nsteps; ++i) {
                 fftw_amd_step_desc d = p->steps[i];
                 void *st = p->stream;
@@ -2243,6 +2293,13 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
                 if (events) { events[ev] = fa_hip_event_create(); fa_hip_event_record(events[ev++], st); }
                 if (pipe && i == p->split - 1) fa_hip_event_record(p->ev_a[slot], st);
                 if (pipe && i == p->nsteps - 1) fa_hip_event_record(p->ev_b[slot], st);
+            }
+            if (hpipe && !ev_out[c]) {
+                const i64 lo = Lout.lo + cs * hp_obs, len = (cn - 1) * hp_obs + hp_ospan;
+                ev_out[c] = fa_hip_event_create();
+                fa_hip_event_record(ev_out[c], p->stream);
+                fa_hip_stream_wait_event(p->hstream[1], ev_out[c]);
+                fa_hip_memcpy_d2h(ro + lo, dout + lo, (size_t)len * sizeof(double), p->hstream[1]);
             }
         }
         if (pipe) {
@@ -2267,6 +2324,18 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
         }
     }
 
+    if (hpipe) {
+        i64 c;
+        fa_hip_stream_sync(p->stream);
+        fa_hip_stream_sync(p->hstream[1]);
+        for (c = 0; c < nhchunks; ++c) {
+            if (ev_in[c]) fa_hip_event_destroy(ev_in[c]);
+            if (ev_out[c]) fa_hip_event_destroy(ev_out[c]);
+        }
+        free(ev_in);
+        free(ev_out);
+        return;
+    }
     if (out_host) stage_d2h(&Lout, host_inplace ? p->stage_in : p->stage_out, ro, out_im_host, p->stream);
     if (in_host || out_host) fa_hip_stream_sync(p->stream);
 }

@@ -855,3 +855,36 @@ def test_pair_launches_of_the_two_pass_plan(torch_dev):
         assert aerror(z2.cpu().numpy(), oracle_dft(x2, (n,), b).reshape(b, n)) < TOL
     finally:
         fa.set_chunk_bytes(0)
+
+
+def test_host_arrays_are_staged_chunk_by_chunk(torch_dev):
+    """dense batched transforms on plain host arrays that run in several chunks: upload, compute and download
+    of different chunks overlap on separate streams (fa_run_locked, host pipeline).  Ordinary launches (2-pass
+    n = 65536), pair launches (n = 2^20), r2c, ragged last chunk; results against the oracle, input untouched."""
+    rng = np.random.default_rng(99)
+    try:
+        for n, b, chunk_bytes in ((1 << 16, 11, 2 << 20), (1 << 20, 5, 32 << 20)):
+            fa.set_chunk_bytes(chunk_bytes)
+            x = crand(rng, b, n)
+            x0 = x.copy()
+            y = np.zeros_like(x)
+            p = fa.plan_many_dft(1, [n], b, x, None, 1, n, y, None, 1, n, fa.FORWARD)
+            assert 1 < p.chunk < b
+            p.execute()
+            assert np.array_equal(x, x0)
+            assert aerror(y, oracle_dft(x, (n,), b).reshape(b, n)) < TOL, n
+            # new arrays, again (streams and staging buffers are reused)
+            x2 = crand(rng, b, n)
+            y2 = np.zeros_like(x2)
+            p.execute_dft(x2, y2)
+            assert aerror(y2, oracle_dft(x2, (n,), b).reshape(b, n)) < TOL, n
+        n, b = 1 << 17, 7
+        fa.set_chunk_bytes(4 << 20)
+        xr = rrand(rng, b, n)
+        yr = np.zeros((b, n // 2 + 1), dtype=np.complex128)
+        p = fa.plan_many_dft_r2c(1, [n], b, xr, None, 1, n, yr, None, 1, n // 2 + 1)
+        assert 1 <= p.chunk < b
+        p.execute()
+        assert aerror(yr, oracle_r2c(xr, (n,), b).reshape(b, n // 2 + 1)) < TOL
+    finally:
+        fa.set_chunk_bytes(0)
