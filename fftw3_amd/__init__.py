@@ -178,6 +178,8 @@ _sig("fftw_amd_plan_sync", None, _vp)
 _sig("fftw_amd_plan_workspace_bytes", C.c_size_t, _vp)
 _sig("fftw_amd_set_chunk_bytes", None, C.c_size_t)
 _sig("fftw_amd_plan_paired", C.c_int, _vp)
+_sig("fftw_amd_set_device", C.c_int, C.c_int)
+_sig("fftw_amd_get_device", C.c_int)
 _sig("fftw_amd_plan_num_steps", C.c_int, _vp)
 _sig("fftw_amd_plan_get_step", C.c_int, _vp, C.c_int, C.POINTER(StepDesc))
 _sig("fftw_amd_plan_chunk", C.c_longlong, _vp)

@@ -844,6 +844,14 @@ void *fftw_amd_malloc_device(size_t nbytes) {
     return fa_hip_malloc(nbytes);
 }
 void fftw_amd_free_device(void *p) { fa_hip_free(p); }
+/* device of the calling host thread (hipSetDevice / hipGetDevice): what fftw_amd_malloc_device allocates on and
+   what a plan created afterwards puts its tables and scratch on at its first execution */
+int fftw_amd_set_device(int device) {
+    if (device < 0 || device >= fa_hip_device_count()) return -1;
+    fa_hip_set_device(device);
+    return 0;
+}
+int fftw_amd_get_device(void) { return fa_hip_device_count() > 0 ? fa_hip_get_device() : -1; }
 /* blocking copies, so that a plain C caller of the device path needs no HIP headers */
 void fftw_amd_memcpy_to_device(void *dst_device, const void *src_host, size_t nbytes) {
     if (!nbytes || fa_hip_device_count() <= 0) return;

@@ -25,6 +25,10 @@ int fftw_amd_device_count(void);
    returns pinned host memory so CPU callers keep working (staged path). */
 void *fftw_amd_malloc_device(size_t nbytes);
 void  fftw_amd_free_device(void *p);
+/* Current device of the calling host thread (hipSetDevice / hipGetDevice) for callers without HIP headers:
+   fftw_amd_malloc_device allocates on it.  fftw_amd_set_device returns -1 for a device that does not exist. */
+int   fftw_amd_set_device(int device);
+int   fftw_amd_get_device(void);
 /* Blocking host <-> device copies (hipMemcpy), so that a C caller of the device path needs no
    HIP headers of its own. */
 void  fftw_amd_memcpy_to_device(void *dst_device, const void *src_host, size_t nbytes);
