@@ -435,6 +435,58 @@ __global__ void __launch_bounds__(256) c2r_pre_kernel(const RealArgs a) {
 }
 
 
+/* The same two butterflies for the layout the large 1-D plans produce (interleaved complex on both sides,
+   contiguous in k, the batch as the only loop, no r2r hook): 16-byte accesses, 32-bit index arithmetic, one
+   work-item per pair (k, h-k); nontemporal on the caller's side.  Pure streaming. */
+struct Real2Fast {
+    const double *src;
+    double *dst;
+    i64 sbatch, dbatch;
+    unsigned h, npair;
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    int tw_shift;
+};
+template <bool NT>
+__global__ void __launch_bounds__(256) r2c_post_fast_kernel(const Real2Fast a) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= a.npair) return;
+    const unsigned h = a.h, km = h - k;
+    const double *s = a.src + (i64)blockIdx.y * a.sbatch;
+    double *d = a.dst + (i64)blockIdx.y * a.dbatch;
+    cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (i64)k);
+    cplx zk = ld_cplx<false>(s + 2 * (i64)k);
+    cplx zm = ld_cplx<false>(s + 2 * (i64)(km == h ? 0 : km));
+    cplx E = c_make(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+    cplx D = c_make(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
+    cplx P = c_mulc(c_mni(D), w);
+    cplx yk = c_add(E, P);
+    cplx ym = c_sub(E, P);
+    ym.y = -ym.y;
+    if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+    st_cplx<NT>(d + 2 * (i64)k, yk);
+    if (km != k) st_cplx<NT>(d + 2 * (i64)km, ym);
+}
+template <bool NT>
+__global__ void __launch_bounds__(256) c2r_pre_fast_kernel(const Real2Fast a) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= a.npair) return;
+    const unsigned h = a.h, km = h - k;
+    const double *s = a.src + (i64)blockIdx.y * a.sbatch;
+    double *d = a.dst + (i64)blockIdx.y * a.dbatch;
+    cplx w = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (i64)k);
+    cplx yk = ld_cplx<NT>(s + 2 * (i64)k), ym = ld_cplx<NT>(s + 2 * (i64)km);
+    if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+    cplx E = c_make(yk.x + ym.x, yk.y - ym.y);
+    cplx D = c_make(yk.x - ym.x, yk.y + ym.y);
+    cplx iO = c_mpi(c_mul(D, w));
+    cplx zk = c_add(E, iO);
+    cplx zm = c_sub(E, iO);
+    zm.y = -zm.y;
+    st_cplx<false>(d + 2 * (i64)k, zk);
+    if (km != k && km != h) st_cplx<false>(d + 2 * (i64)km, zm);
+}
+
 /* ------------------------------------------------------------------------ */
 /* r2r pre / post processing                                                 */
 /* ------------------------------------------------------------------------ */
@@ -1377,6 +1429,30 @@ static int launch_step_kind(const fftw_amd_step_desc *d, double *const *bufs,
         ra.tw_hi = (const cplx *)tables[d->tw_hi];
         ra.tw_shift = d->tw_shift;
         ra.flags = d->flags;
+        {
+            /* streaming form for the layout of the large 1-D plans (see r2c_post_fast_kernel) */
+            const bool r2c = d->kind == FFTW_AMD_STEP_R2C_POST;
+            const int swap_mask = FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_CONJ_OUT | FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT;
+            if (ra.r2r == 0 && ra.twmul == 1 && ra.src_im == 1 && ra.dst_im == 1 && ra.is_k == 2 && ra.os_k == 2 &&
+                !(d->flags & swap_mask) && d->ndims == 1 && bd == 0 && d->kpos == 0 && ra.h >= 2 && ra.h < (1LL << 30) &&
+                cn > 0 && cn < 65536 && (d->dim_is[0] % 2) == 0 && (d->dim_os[0] % 2) == 0 &&
+                ((uintptr_t)ra.src % 16) == 0 && ((uintptr_t)ra.dst % 16) == 0) {
+                Real2Fast f2;
+                f2.src = ra.src; f2.dst = ra.dst;
+                f2.sbatch = d->dim_is[0]; f2.dbatch = d->dim_os[0];
+                f2.h = (unsigned)ra.h; f2.npair = (unsigned)ra.npair;
+                f2.tw_lo = ra.tw_lo; f2.tw_hi = ra.tw_hi; f2.tw_shift = ra.tw_shift;
+                dim3 g((f2.npair + 255) / 256, (unsigned)cn, 1);
+                if (r2c) {
+                    if (d->flags & FFTW_AMD_F_NT_OUT) hipLaunchKernelGGL(r2c_post_fast_kernel<true>, g, dim3(256), 0, st, f2);
+                    else hipLaunchKernelGGL(r2c_post_fast_kernel<false>, g, dim3(256), 0, st, f2);
+                } else {
+                    if (d->flags & FFTW_AMD_F_NT_IN) hipLaunchKernelGGL(c2r_pre_fast_kernel<true>, g, dim3(256), 0, st, f2);
+                    else hipLaunchKernelGGL(c2r_pre_fast_kernel<false>, g, dim3(256), 0, st, f2);
+                }
+                return 0;
+            }
+        }
         dim3 grid;
         if (!elem_fill(&ra.e, d, ra.npair, cn, d->kpos, &grid)) return 0;
         if (d->kind == FFTW_AMD_STEP_R2C_POST)

@@ -481,8 +481,11 @@ def test_gpu_r2r_r2hc_equals_r2c_large():
     p.sync()
     hc = hc.view(hm, n)
     spec = spec.view(hm, n // 2 + 1)
-    assert torch.equal(hc[:, :n // 2 + 1], spec.real)
-    assert torch.equal(hc[:, n // 2 + 1:], torch.flip(spec.imag[:, 1:n // 2], dims=[1]))
+    # the two plans end in different kernels (untangle with the R2HC epilogue / streaming untangle): the same
+    # arithmetic, but not necessarily the same FMA contractions -- equal to rounding, not bit for bit
+    scale = spec.abs().max().item()
+    assert (hc[:, :n // 2 + 1] - spec.real).abs().max().item() <= 8e-16 * scale
+    assert (hc[:, n // 2 + 1:] - torch.flip(spec.imag[:, 1:n // 2], dims=[1])).abs().max().item() <= 8e-16 * scale
 
 
 @pytest.mark.gpu
