@@ -44,12 +44,12 @@ void fftw_amd_plan_sync(fftw_plan p);
 /* Bytes of device scratch the plan owns (twiddle tables + work buffers). */
 size_t fftw_amd_plan_workspace_bytes(const fftw_plan p);
 
-/* Upper bound, in bytes, for the scratch that one chunk of a multi-pass plan
-   may occupy (default 1 GiB; three such slots are pipelined).  Measured on
-   MI355X: smaller chunks keep the intermediate in the Infinity Cache but gain
-   nothing, because cache hits and HBM misses share the ~7 TB/s fabric
-   (profiles/r01_membw.txt), while they pay more launches.  0 restores the
-   default.  Affects plans created afterwards. */
+/* Upper bound, in bytes, for the scratch that one chunk of a multi-pass plan may occupy (default
+   256 MiB).  Measured on MI355X: with the caller's input and output streamed with nontemporal
+   accesses, a 256 MiB scratch image written by one pass is still in the Infinity Cache when the next
+   pass reads it (N = 2^20: 12.7 -> 11.4 us per transform); larger chunks lose that, smaller ones pay
+   more launches (profiles/r02_chunk_nt_sweep.txt).  FFTW_MEASURE searches
+   128 MiB ... 4 GiB.  0 restores the default.  Affects plans created afterwards. */
 void fftw_amd_set_chunk_bytes(size_t nbytes);
 
 /* ---- batch sharding over the GPUs of one node ----------------------
