@@ -432,3 +432,49 @@ def test_wisdom_key_of_rank8_plan_with_huge_strides_stays_in_bounds():
     dims = [(1, big + i, big - i) for i in range(7)] + [(8, 1, 1)]
     p = fa.plan_guru64_dft(dims, [], x, y, fa.FORWARD, fa.ESTIMATE)
     run_plan_on_host(p, x, y)
+
+
+def _pass_lengths(p):
+    return [s.L for s in p.steps() if s.kind == 1]
+
+
+def test_split_models_keep_the_factorisation_exact_and_prefer_measured_winners():
+    """the measured cost models (split_costs.inc / split2_costs.inc) only reorder and re-factor passes:
+    the product of the pass lengths is n, every length has a register kernel; spot checks of picks the
+    sweeps established (profiles/r02_*_split_samples.jsonl)"""
+    x = np.zeros(4, dtype=complex)
+    for n in (1 << 14, 1 << 16, 1 << 17, 1 << 19, 1 << 20, 1 << 21, 10 ** 4, 10 ** 5, 10 ** 6, 60060, 518400,
+              15375360, 10 ** 7, 6 ** 9, 14817600, 1080 * 1024, 2000 * 1000):
+        p = fa.plan_many_dft(1, [n], 64, x, None, 1, n, x.copy(), None, 1, n, fa.FORWARD)
+        lens = _pass_lengths(p)
+        assert int(np.prod([int(v) for v in lens])) == n, (n, lens)
+        assert all("lds" not in l for l in p.sprint().splitlines()[1:]), p.sprint()
+    lens = lambda n: _pass_lengths(fa.plan_many_dft(1, [n], 64, x, None, 1, n, x.copy(), None, 1, n, fa.FORWARD))
+    assert lens(1 << 16) == [128, 512]                    # not 256 x 256: the 256-point kernel is the slow one
+    assert lens(1 << 20) == [1024, 1024]
+    assert lens(1 << 21) == [2048, 1024]                  # two trips through the narrow-tile 2048-point kernel
+    three = lens(15375360)
+    assert len(three) == 3 and three[0] % 8 == 0          # first length on the 128-byte grid
+    # a strided axis of 1025 ... 2048 points runs in one trip (the 1080 of a 1080 x 1920 image)
+    p = fa.plan_many_dft(2, [1080, 1920], 4, x, None, 1, 1080 * 1920, x.copy(), None, 1, 1080 * 1920, fa.FORWARD)
+    assert _pass_lengths(p) == [1920, 1080], p.sprint()
+
+
+def test_streaming_access_flags_only_on_the_callers_side_and_only_for_large_batches():
+    """FFTW_AMD_F_NT_IN / NT_OUT (mark_streaming_accesses): set on the step that reads the caller's input once
+    and on the step that writes the output nobody reads back, never on scratch traffic, and not at all when the
+    whole batch is small enough to stay cached"""
+    NT_IN, NT_OUT = 1 << 12, 1 << 13
+    x = np.zeros(4, dtype=complex)
+    n = 1 << 20
+    small = fa.plan_many_dft(1, [n], 4, x, None, 1, n, x.copy(), None, 1, n, fa.FORWARD)       # 128 MiB touched
+    assert all(not (s.flags & (NT_IN | NT_OUT)) for s in small.steps())
+    big = fa.plan_many_dft(1, [n], 64, x, None, 1, n, x.copy(), None, 1, n, fa.FORWARD)        # 2 GiB touched
+    st = big.steps()
+    assert st[0].src_buf == 0 and (st[0].flags & NT_IN) and not (st[0].flags & NT_OUT)         # writes scratch
+    assert st[-1].dst_buf == 1 and (st[-1].flags & NT_OUT) and not (st[-1].flags & NT_IN)      # reads scratch
+    # 2-D: the first axis writes the output array that the second axis reads back: no NT_OUT there
+    p2 = fa.plan_many_dft(2, [4096, 4096], 8, x, None, 1, 1 << 24, x.copy(), None, 1, 1 << 24, fa.FORWARD)
+    s2 = p2.steps()
+    assert s2[0].dst_buf == 1 and not (s2[0].flags & NT_OUT)
+    assert s2[-1].dst_buf == 1 and (s2[-1].flags & NT_OUT)
