@@ -487,6 +487,67 @@ __global__ void __launch_bounds__(256) c2r_pre_fast_kernel(const Real2Fast a) {
     if (km != k && km != h) st_cplx<false>(d + 2 * (i64)km, zm);
 }
 
+/* DCT-II / DST-II (REDFT10 / RODFT10) of long contiguous rows, streaming forms of the two element-wise steps
+   (reference loops: reodft010e-r2hc, fftw/fftw_api.c:12465-12660):
+   shuffle   v[j] = x[2j], v[n-1-j] = +-x[2j+1]: one work-item per input quad, 2 x 16 B in, 2 x 16 B out;
+   untangle + epilogue: one work-item per pair (k, h-k) of the half-length spectrum Z (h = n / 2): Y[k], Y[h-k]
+   as in r2c_post_fast_kernel, then y[k] = 2 Re(w^k Y[k]), y[n-k] = -2 Im(w^k Y[k]) with w = w_4n (the table's
+   modulus; the untangle twiddle is its entry 4k, and w^(h-k) = e^(i pi/4) conj(w^k) saves a table lookup). */
+struct DctFast {
+    const double *src;
+    double *dst;
+    i64 sbatch, dbatch;
+    unsigned n, nitems;
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    int tw_shift;
+    int odd;            /* RODFT10: negate the odd samples / reverse the output */
+};
+template <bool NT>
+__global__ void __launch_bounds__(256) dct2_shuffle_fast_kernel(const DctFast a) {
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= a.nitems) return;
+    const double *s = a.src + (i64)blockIdx.y * a.sbatch + 4 * (i64)q;
+    double *d = a.dst + (i64)blockIdx.y * a.dbatch;
+    cplx u = ld_cplx<NT>(s), v = ld_cplx<NT>(s + 2);
+    const double sg = a.odd ? -1.0 : 1.0;
+    st_cplx<false>(d + 2 * (i64)q, c_make(u.x, v.x));
+    st_cplx<false>(d + ((i64)a.n - 2 - 2 * (i64)q), c_make(sg * v.y, sg * u.y));
+}
+FA_DEV void dct2_epilogue(const DctFast &a, double *d, unsigned idx, cplx Y, cplx w) {
+    const unsigned n = a.n;
+    const bool mid = idx > 0 && 2 * idx < n;
+    const double vi = mid ? Y.y : 0.0;
+    const double dr = Y.x * w.x + vi * w.y, di = vi * w.x - Y.x * w.y;
+    d[a.odd ? n - 1 - idx : idx] = 2.0 * dr;
+    if (mid) d[a.odd ? idx - 1 : n - idx] = -2.0 * di;
+}
+template <bool NT>
+__global__ void __launch_bounds__(256) dct2_untangle_fast_kernel(const DctFast a) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= a.nitems) return;
+    const unsigned h = a.n / 2, km = h - k;
+    const double *s = a.src + (i64)blockIdx.y * a.sbatch;
+    double *d = a.dst + (i64)blockIdx.y * a.dbatch;
+    cplx wu = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 4 * (i64)k);      /* w_n^k */
+    cplx wk = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (i64)k);          /* w_4n^k */
+    cplx zk = ld_cplx<false>(s + 2 * (i64)k);
+    cplx zm = ld_cplx<false>(s + 2 * (i64)(km == h ? 0 : km));
+    cplx E = c_make(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+    cplx D = c_make(0.5 * (zk.x - zm.x), 0.5 * (zk.y + zm.y));
+    cplx P = c_mulc(c_mni(D), wu);
+    cplx yk = c_add(E, P);
+    cplx ym = c_sub(E, P);
+    ym.y = -ym.y;
+    if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+    dct2_epilogue(a, d, k, yk, wk);
+    if (km != k) {
+        /* w_4n^(h-k) = w_4n^(n/2) conj(w_4n^k), w_4n^(n/2) = (cos, sin)(pi/4) */
+        const cplx wm = c_make(FA_SQRT1_2 * (wk.x + wk.y), FA_SQRT1_2 * (wk.x - wk.y));
+        dct2_epilogue(a, d, km, ym, wm);
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* r2r pre / post processing                                                 */
 /* ------------------------------------------------------------------------ */
@@ -1429,6 +1490,21 @@ static int launch_step_kind(const fftw_amd_step_desc *d, double *const *bufs,
         ra.tw_hi = (const cplx *)tables[d->tw_hi];
         ra.tw_shift = d->tw_shift;
         ra.flags = d->flags;
+        if (d->kind == FFTW_AMD_STEP_R2C_POST && (ra.r2r == FFTW_AMD_R2R_POST_E10 || ra.r2r == FFTW_AMD_R2R_POST_O10) &&
+            ra.twmul == 4 && ra.src_im == 1 && ra.is_k == 2 && ra.os_k == 1 && ra.rn == 2 * ra.h && ra.h >= 4 && ra.h % 2 == 0 &&
+            ra.rn < (1LL << 31) && d->ndims == 1 && bd == 0 && d->kpos == 0 && cn > 0 && cn < 65536 &&
+            (d->dim_is[0] % 2) == 0 && ((uintptr_t)ra.src % 16) == 0 &&
+            !(d->flags & (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_CONJ_OUT))) {
+            /* DCT-II / DST-II: streaming untangle + epilogue (dct2_untangle_fast_kernel) */
+            DctFast f;
+            f.src = ra.src; f.dst = ra.dst; f.sbatch = d->dim_is[0]; f.dbatch = d->dim_os[0];
+            f.n = (unsigned)ra.rn; f.nitems = (unsigned)ra.npair;
+            f.tw_lo = ra.tw_lo; f.tw_hi = ra.tw_hi; f.tw_shift = ra.tw_shift;
+            f.odd = ra.r2r == FFTW_AMD_R2R_POST_O10;
+            dim3 g((f.nitems + 255) / 256, (unsigned)cn, 1);
+            hipLaunchKernelGGL(dct2_untangle_fast_kernel<false>, g, dim3(256), 0, st, f);
+            return 0;
+        }
         {
             /* streaming form for the layout of the large 1-D plans (see r2c_post_fast_kernel) */
             const bool r2c = d->kind == FFTW_AMD_STEP_R2C_POST;
@@ -1540,6 +1616,20 @@ static int launch_step_kind(const fftw_amd_step_desc *d, double *const *bufs,
         ra.tw_hi = (d->tw_hi >= 0) ? (const cplx *)tables[d->tw_hi] : NULL;
         ra.tw_shift = d->tw_shift;
         ra.mode = d->variant;
+        if ((ra.mode == FFTW_AMD_R2R_PRE_E10 || ra.mode == FFTW_AMD_R2R_PRE_O10) && ra.is_k == 1 && ra.os_k == 2 &&
+            ra.dst_im == 1 && ra.n >= 8 && ra.n % 4 == 0 && ra.n < (1LL << 31) && d->ndims == 1 && bd == 0 && d->kpos == 0 &&
+            cn > 0 && cn < 65536 && (d->dim_is[0] % 2) == 0 && (d->dim_os[0] % 2) == 0 &&
+            ((uintptr_t)ra.src % 16) == 0 && ((uintptr_t)ra.dst % 16) == 0) {
+            DctFast f;
+            f.src = ra.src; f.dst = ra.dst; f.sbatch = d->dim_is[0]; f.dbatch = d->dim_os[0];
+            f.n = (unsigned)ra.n; f.nitems = (unsigned)(ra.n / 4);
+            f.tw_lo = NULL; f.tw_hi = NULL; f.tw_shift = 0;
+            f.odd = ra.mode == FFTW_AMD_R2R_PRE_O10;
+            dim3 g((f.nitems + 255) / 256, (unsigned)cn, 1);
+            if (d->flags & FFTW_AMD_F_NT_IN) hipLaunchKernelGGL(dct2_shuffle_fast_kernel<true>, g, dim3(256), 0, st, f);
+            else hipLaunchKernelGGL(dct2_shuffle_fast_kernel<false>, g, dim3(256), 0, st, f);
+            return 0;
+        }
         dim3 grid;
         if (!elem_fill(&ra.e, d, ra.K, cn, d->kpos, &grid)) return 0;
         hipLaunchKernelGGL(r2r_kernel, grid, dim3(256), 0, st, ra);
