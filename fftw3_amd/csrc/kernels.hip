@@ -962,10 +962,18 @@ extern "C" int fa_hip_device_count(void) {
     return g_dev_count;
 }
 
+/* NULL when the device cannot provide the memory (the planners then return NULL, like the reference's
+   planner does when a solver's buffers cannot be had); every other HIP error is fatal */
 extern "C" void *fa_hip_malloc(size_t nbytes) {
     void *p = NULL;
     if (nbytes == 0) nbytes = 16;
-    FA_CHECK(hipMalloc(&p, nbytes));
+    hipError_t e = hipMalloc(&p, nbytes);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+        (void)hipGetLastError();
+        fprintf(stderr, "fftw3_amd: the device cannot allocate %zu bytes\n", nbytes);
+        return NULL;
+    }
+    FA_CHECK(e);
     return p;
 }
 

@@ -92,7 +92,14 @@ static void plan_reset_build(plan *p) {
 void fa_plan_free(plan *p) {
     int i;
     if (!p) return;
-    if (p->dev_ready || p->stage_in || p->stage_out) {
+    {
+        /* device resources may exist without dev_ready (fa_device_init gave up half way: out of device memory) */
+        int any = p->dev_ready || p->stage_in || p->stage_out || p->hstream[0] || p->pstream[0];
+        for (i = 0; i < p->ntabs && !any; ++i) any = p->tabs[i].dev != NULL;
+        for (i = 2; i < p->nbufs && !any; ++i) any = p->dbuf[i] != NULL;
+        if (!any) goto host_only;
+    }
+    {
         fa_hip_stream_sync(p->stream);
         for (i = 0; i < p->ntabs; ++i) fa_hip_free(p->tabs[i].dev);
         for (i = 2; i < p->nbufs; ++i) fa_hip_free(p->dbuf[i]);
@@ -109,6 +116,7 @@ void fa_plan_free(plan *p) {
             fa_hip_stream_destroy(p->pstream[1]);
         }
     }
+host_only:
     for (i = 0; i < p->ntabs; ++i) free(p->tabs[i].host);
     free(p->steps);
     pthread_mutex_destroy(&p->lock);
@@ -1977,6 +1985,7 @@ int fa_device_init(plan *p) {
         size_t bytes = (size_t)t->len * (t->kind == FA_TAB_PERM ? sizeof(i64) : 2 * sizeof(double));
         if (t->dev) continue;
         t->dev = fa_hip_malloc(bytes);
+        if (!t->dev) return -1;
         if (t->kind == FA_TAB_DFT_OF) continue;    /* second sweep */
         fa_hip_memcpy_h2d(t->dev, t->host, bytes, p->stream);
     }
@@ -2034,8 +2043,10 @@ int fa_device_init(plan *p) {
         }
     }
     for (i = 2; i < p->nbufs; ++i)
-        if (!p->dbuf[i])
+        if (!p->dbuf[i]) {
             p->dbuf[i] = (double *)fa_hip_malloc((size_t)p->buf_reals[i] * sizeof(double) * (size_t)p->nslots);
+            if (!p->dbuf[i]) return -1;
+        }
     p->dev_ready = 1;
     return 0;
 }
@@ -2092,6 +2103,10 @@ static double *stage_buf(double **slot, size_t *have, size_t need) {
     if (*have < need) {
         fa_hip_free(*slot);
         *slot = (double *)fa_hip_malloc(need);
+        if (!*slot) {
+            fprintf(stderr, "fftw3_amd: no device memory to stage the host arrays of this execution\n");
+            abort();
+        }
         *have = need;
     }
     return *slot;

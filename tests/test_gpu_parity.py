@@ -888,3 +888,26 @@ def test_host_arrays_are_staged_chunk_by_chunk(torch_dev):
         assert aerror(yr, oracle_r2c(xr, (n,), b).reshape(b, n // 2 + 1)) < TOL
     finally:
         fa.set_chunk_bytes(0)
+
+
+def test_planner_returns_null_when_the_device_is_out_of_memory(torch_dev):
+    """tables and scratch are allocated at plan time: when the device cannot provide them the planner returns
+    NULL (as every fftw_plan_* call may, fftw3.h) instead of aborting, and nothing leaks"""
+    torch, dev = torch_dev
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(0, free0 - (160 << 20)), dtype=torch.uint8, device=dev)     # leave ~160 MiB
+    try:
+        n, b = 1 << 20, 64
+        x = torch.zeros(8, dtype=torch.complex128, device=dev)      # the planner only needs addresses
+        with pytest.raises(ValueError):
+            fa.plan_many_dft(1, [n], b, x, None, 1, n, x, None, 1, n, fa.FORWARD)      # needs 2 x 256 MiB of scratch
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 > (96 << 20)                                   # the failed plan gave its tables back
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    # and planning works again afterwards
+    rng = np.random.default_rng(4)
+    xs = crand(rng, 2, 4096)
+    assert aerror(gpu_c2c(torch_dev, xs, (4096,), 2), oracle_dft(xs, (4096,), 2).reshape(2, 4096)) < TOL
