@@ -548,6 +548,51 @@ __global__ void __launch_bounds__(256) dct2_untangle_fast_kernel(const DctFast a
     }
 }
 
+/* DCT-III / DST-III (REDFT01 / RODFT01) of long contiguous rows, the transposes of the two kernels above:
+   prologue + tangle: Y[idx] = conj-twiddled (x[idx], x[n-idx]) (pro_load, r2r_epi.hpp), then the c2r tangle of
+   the pair (k, h-k); unshuffle: y[2j] = v[j], y[2j+1] = +-v[n-1-j], one work-item per output quad. */
+FA_DEV cplx dct3_prologue(const DctFast &a, const double *s, unsigned idx, cplx w) {
+    const unsigned n = a.n;
+    double x, y;
+    if (!a.odd) { x = s[idx]; y = idx > 0 ? s[n - idx] : 0.0; }
+    else { x = s[n - 1 - idx]; y = idx > 0 ? s[idx - 1] : 0.0; }
+    return c_make(x * w.x + y * w.y, x * w.y - y * w.x);
+}
+template <bool NT>
+__global__ void __launch_bounds__(256) dct3_tangle_fast_kernel(const DctFast a) {
+    const unsigned k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= a.nitems) return;
+    const unsigned h = a.n / 2, km = h - k;
+    const double *s = a.src + (i64)blockIdx.y * a.sbatch;
+    double *d = a.dst + (i64)blockIdx.y * a.dbatch;
+    cplx wu = tw2(a.tw_lo, a.tw_hi, a.tw_shift, 4 * (i64)k);      /* w_n^k */
+    cplx wk = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (i64)k);          /* w_4n^k */
+    const cplx wm = c_make(FA_SQRT1_2 * (wk.x + wk.y), FA_SQRT1_2 * (wk.x - wk.y));   /* w_4n^(h-k) */
+    cplx yk = dct3_prologue(a, s, k, wk);
+    cplx ym = dct3_prologue(a, s, km, wm);
+    if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+    cplx E = c_make(yk.x + ym.x, yk.y - ym.y);
+    cplx D = c_make(yk.x - ym.x, yk.y + ym.y);
+    cplx iO = c_mpi(c_mul(D, wu));
+    cplx zk = c_add(E, iO);
+    cplx zm = c_sub(E, iO);
+    zm.y = -zm.y;
+    st_cplx<false>(d + 2 * (i64)k, zk);
+    if (km != k && km != h) st_cplx<false>(d + 2 * (i64)km, zm);
+}
+template <bool NT>
+__global__ void __launch_bounds__(256) dct3_unshuffle_fast_kernel(const DctFast a) {
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= a.nitems) return;
+    const double *s = a.src + (i64)blockIdx.y * a.sbatch;
+    double *d = a.dst + (i64)blockIdx.y * a.dbatch + 4 * (i64)q;
+    cplx lo = ld_cplx<false>(s + 2 * (i64)q);                          /* v[2q], v[2q+1] */
+    cplx hi = ld_cplx<false>(s + ((i64)a.n - 2 - 2 * (i64)q));         /* v[n-2-2q], v[n-1-2q] */
+    const double sg = a.odd ? -1.0 : 1.0;
+    st_cplx<NT>(d, c_make(lo.x, sg * hi.y));
+    st_cplx<NT>(d + 2, c_make(lo.y, sg * hi.x));
+}
+
 /* ------------------------------------------------------------------------ */
 /* r2r pre / post processing                                                 */
 /* ------------------------------------------------------------------------ */
@@ -1513,6 +1558,21 @@ static int launch_step_kind(const fftw_amd_step_desc *d, double *const *bufs,
             hipLaunchKernelGGL(dct2_untangle_fast_kernel<false>, g, dim3(256), 0, st, f);
             return 0;
         }
+        if (d->kind == FFTW_AMD_STEP_C2R_PRE && (ra.r2r == FFTW_AMD_R2R_PRE_E01 || ra.r2r == FFTW_AMD_R2R_PRE_O01) &&
+            ra.twmul == 4 && ra.dst_im == 1 && ra.os_k == 2 && ra.is_k == 1 && ra.rn == 2 * ra.h && ra.h >= 4 && ra.h % 2 == 0 &&
+            ra.rn < (1LL << 31) && d->ndims == 1 && bd == 0 && d->kpos == 0 && cn > 0 && cn < 65536 &&
+            (d->dim_os[0] % 2) == 0 && ((uintptr_t)ra.dst % 16) == 0 &&
+            !(d->flags & (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT | FFTW_AMD_F_CONJ_OUT | FFTW_AMD_F_REAL_OUT))) {
+            /* DCT-III / DST-III: streaming prologue + tangle (dct3_tangle_fast_kernel) */
+            DctFast f;
+            f.src = ra.src; f.dst = ra.dst; f.sbatch = d->dim_is[0]; f.dbatch = d->dim_os[0];
+            f.n = (unsigned)ra.rn; f.nitems = (unsigned)ra.npair;
+            f.tw_lo = ra.tw_lo; f.tw_hi = ra.tw_hi; f.tw_shift = ra.tw_shift;
+            f.odd = ra.r2r == FFTW_AMD_R2R_PRE_O01;
+            dim3 g((f.nitems + 255) / 256, (unsigned)cn, 1);
+            hipLaunchKernelGGL(dct3_tangle_fast_kernel<false>, g, dim3(256), 0, st, f);
+            return 0;
+        }
         {
             /* streaming form for the layout of the large 1-D plans (see r2c_post_fast_kernel) */
             const bool r2c = d->kind == FFTW_AMD_STEP_R2C_POST;
@@ -1636,6 +1696,20 @@ static int launch_step_kind(const fftw_amd_step_desc *d, double *const *bufs,
             dim3 g((f.nitems + 255) / 256, (unsigned)cn, 1);
             if (d->flags & FFTW_AMD_F_NT_IN) hipLaunchKernelGGL(dct2_shuffle_fast_kernel<true>, g, dim3(256), 0, st, f);
             else hipLaunchKernelGGL(dct2_shuffle_fast_kernel<false>, g, dim3(256), 0, st, f);
+            return 0;
+        }
+        if ((ra.mode == FFTW_AMD_R2R_POST_E01 || ra.mode == FFTW_AMD_R2R_POST_O01) && ra.is_k == 2 && ra.src_im == 1 &&
+            ra.os_k == 1 && ra.n >= 8 && ra.n % 4 == 0 && ra.n < (1LL << 31) && d->ndims == 1 && bd == 0 && d->kpos == 0 &&
+            cn > 0 && cn < 65536 && (d->dim_is[0] % 2) == 0 && (d->dim_os[0] % 2) == 0 &&
+            ((uintptr_t)ra.src % 16) == 0 && ((uintptr_t)ra.dst % 16) == 0) {
+            DctFast f;
+            f.src = ra.src; f.dst = ra.dst; f.sbatch = d->dim_is[0]; f.dbatch = d->dim_os[0];
+            f.n = (unsigned)ra.n; f.nitems = (unsigned)(ra.n / 4);
+            f.tw_lo = NULL; f.tw_hi = NULL; f.tw_shift = 0;
+            f.odd = ra.mode == FFTW_AMD_R2R_POST_O01;
+            dim3 g((f.nitems + 255) / 256, (unsigned)cn, 1);
+            if (d->flags & FFTW_AMD_F_NT_OUT) hipLaunchKernelGGL(dct3_unshuffle_fast_kernel<true>, g, dim3(256), 0, st, f);
+            else hipLaunchKernelGGL(dct3_unshuffle_fast_kernel<false>, g, dim3(256), 0, st, f);
             return 0;
         }
         dim3 grid;
