@@ -108,9 +108,10 @@ int main(int argc, char **argv) {
             {"nnnn", k_col<1, 1>, k_row<1, 1>},
             {"nppn", k_col<1, 0>, k_row<0, 1>},
             {"pnnp", k_col<0, 1>, k_row<1, 0>},
+            {"npnn", k_col<1, 0>, k_row<1, 1>},
         };
-        int Cs[] = {2, 4, 8, 16, 64};
-        for (int C : Cs) for (auto &p : pols) for (int G : {-1, 16}) for (int streams : {1, 2}) {
+        int Cs[] = {8, 16, 24, 32};
+        for (int C : Cs) for (auto &p : pols) for (int G : {-1}) for (int streams : {1}) {
             i64 nt = (i64)C * 128;
             if (G > 0 && (nt / 8) % G) continue;
             auto run = [&] {
