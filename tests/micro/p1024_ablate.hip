@@ -66,6 +66,55 @@ __global__ void __launch_bounds__(256, 2) pass1024_persist(const P1024Args a, in
         __syncthreads();
     }
 }
+/* persistent with DYNAMIC tile fetching: one ticket counter per XCD (blockIdx & 7), the next ticket is fetched
+   while the current tile is processed; keeps the XCD-contiguous order and has no static imbalance */
+template <bool IN_T, bool OUT_T, int HAS_TW>
+__global__ void __launch_bounds__(256, 2) pass1024_dyn(const P1024Args a, int total, unsigned *counters) {
+    extern __shared__ __attribute__((aligned(16))) double plane[];
+    __shared__ unsigned s_ticket;
+    const int x = blockIdx.x & 7, per = total >> 3;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&counters[x], 1u);
+    __syncthreads();
+    unsigned k = s_ticket;
+    while (k < (unsigned)per) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_ticket = atomicAdd(&counters[x], 1u);      /* next ticket: latency hidden by this tile */
+        unsigned blk = (unsigned)(x * per) + k;
+        unsigned tile = blk % (unsigned)a.ntiles, rest = blk / (unsigned)a.ntiles;
+        i64 soff = (i64)rest * a.dis[1], doff = (i64)rest * a.dos[1], twb = (i64)rest * a.dtw[1];
+        const i64 t0 = (i64)tile * 8;
+        P1024Tile t;
+        t.lo_sh = 0; t.lo_is = 0; t.lo_os = 0;
+        t.src = a.src + soff + t0 * a.dis[0];
+        t.dst = a.dst + doff + t0 * a.dos[0];
+        t.is_l = a.is_l; t.os_l = a.os_l;
+        t.dis0 = a.dis[0]; t.dos0 = a.dos[0];
+        t.dtw0 = a.dtw[0]; t.q0 = twb + t0 * a.dtw[0];
+        t.w1024 = a.w1024; t.tw_lo = a.tw_lo; t.tw_hi = a.tw_hi; t.tw_shift = a.tw_shift;
+        t.Tcur = 8; t.flags = a.flags; t.dbg = NULL;
+        p1024_tile<IN_T, OUT_T, HAS_TW, 0>(t, plane, threadIdx.x);
+        __syncthreads();
+        k = s_ticket;
+    }
+}
+static unsigned *g_counters = NULL;
+static void launch_pair_dyn(const double *in, double *scr, double *out, int C, const cplx *w, const cplx *lo,
+                            const cplx *hi, int nt, hipStream_t st) {
+    P1024Args a1, a2;
+    fill_args(a1, in, scr, true, C, w, lo, hi, nt);
+    fill_args(a2, scr, out, false, C, w, lo, hi, nt);
+    const size_t lds = FA_P1024_LDS_DOUBLES * sizeof(double);
+    static bool done = false;
+    if (!done) {
+        FA_CHECK(hipFuncSetAttribute((const void *)pass1024_dyn<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass1024_dyn<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FA_CHECK(hipMalloc(&g_counters, 64));
+        done = true;
+    }
+    FA_CHECK(hipMemsetAsync(g_counters, 0, 64, st));
+    hipLaunchKernelGGL((pass1024_dyn<true, true, 0>), dim3(512), dim3(256), lds, st, a1, 128 * C, g_counters);
+    hipLaunchKernelGGL((pass1024_dyn<false, true, 2>), dim3(512), dim3(256), lds, st, a2, 128 * C, g_counters + 8);
+}
 static void launch_pair_persist(const double *in, double *scr, double *out, int C, const cplx *w, const cplx *lo,
                                 const cplx *hi, int nt, hipStream_t st) {
     P1024Args a1, a2;
@@ -143,7 +192,8 @@ int main() {
     hipStream_t st; FA_CHECK(hipStreamCreate(&st));
     hipEvent_t e0, e1; FA_CHECK(hipEventCreate(&e0)); FA_CHECK(hipEventCreate(&e1));
     struct V { const char *name; pairfn f; };
-    V vs[] = { {"product kernel", launch_pair<0>}, {"persistent 2 WG/CU", launch_pair_persist}, {"no butterflies", launch_pair<1>}, {"no twiddles", launch_pair<2>},
+    V vs[] = { {"product kernel", launch_pair<0>}, {"persistent 2 WG/CU", launch_pair_persist}, {"persistent, dynamic tickets", launch_pair_dyn},
+               {"product kernel (again)", launch_pair<0>}, {"dynamic tickets (again)", launch_pair_dyn}, {"no butterflies", launch_pair<1>}, {"no twiddles", launch_pair<2>},
                {"no LDS exchange", launch_pair<4>}, {"no bfly, no tw", launch_pair<3>}, {"memory + LDS only... (1|2)", launch_pair<3>},
                {"memory only (1|2|4)", launch_pair<7>} };
     /* warm-up: the first variant timed in a process reads 3-4 % slow (clocks / page tables), which once made
@@ -153,7 +203,7 @@ int main() {
     FA_CHECK(hipDeviceSynchronize());
     printf("%-28s %4s %3s | %9s %7s\n", "variant", "C", "nt", "us/xform", "whole%");
     for (int nt : {1}) for (int C : {16, 12, 20, 24, 32}) for (auto &v : vs) {
-        if (C != 16 && v.f != (pairfn)launch_pair<0> && v.f != (pairfn)launch_pair_persist) continue;
+        if (C != 16 && v.f != (pairfn)launch_pair<0> && v.f != (pairfn)launch_pair_persist && v.f != (pairfn)launch_pair_dyn) continue;
         auto run = [&] { for (int k = 0; k + 1 <= NT / C; ++k) v.f(in + (i64)k * C * N * 2, scr, out + (i64)k * C * N * 2, C, w, lo, hi, nt, st); };
         run(); FA_CHECK(hipDeviceSynchronize());
         double best = 1e30;
