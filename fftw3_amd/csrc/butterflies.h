@@ -412,4 +412,97 @@ template <> struct Bfly<26> : BflyPFA<2, 13> {};
 template <> struct Bfly<28> : BflyPFA<4, 7> {};
 template <> struct Bfly<30> : BflyPFA<2, 15> {};
 
+/* primes 17, 19, 23: the same symmetric O(p^2) formula (the reference has no codelets for them and runs its
+   generic O(n^2) solver, fftw/fftw_api.c:3390-3448); as radices of the two-stage kernels they take lengths such as
+   136 = 17 x 8 or 17 408 = 128 x 136 off the LDS kernel */
+template <> struct OddTrig<17> {
+    static FA_DEV double c(int k) {
+        const double t[] = { 1.0,
+                             0.9324722294043558045731158918215633862626,
+                             0.7390089172206591159245343098726481057599,
+                             0.4457383557765382673964575493794868554277,
+                             0.09226835946330199523965110715450648036302,
+                             -0.2736629900720828635390779354368134316249,
+                             -0.602634636379256389178588154986840621619,
+                             -0.8502171357296141521341439229493520584707,
+                             -0.9829730996839017782819488448551987160987 };
+        return t[k];
+    }
+    static FA_DEV double s(int k) {
+        const double t[] = { 0.0,
+                             0.3612416661871529487447145961837001637245,
+                             0.6736956436465572117126919124256946158624,
+                             0.8951632913550623220670164997537854569906,
+                             0.9957341762950345218711911789054817839027,
+                             0.9618256431728190704087962907315185500315,
+                             0.7980172272802395033328051127962613693613,
+                             0.526432162877355800244607799140699566171,
+                             0.1837495178165703315744088396207275824891 };
+        return t[k];
+    }
+};
+template <> struct Bfly<17> : BflyOdd<17> {};
+template <> struct OddTrig<19> {
+    static FA_DEV double c(int k) {
+        const double t[] = { 1.0,
+                             0.9458172417006346790196657142849415278238,
+                             0.7891405093963935992189811493990907424327,
+                             0.5469481581224268747117627466961884997789,
+                             0.2454854871407991489222909177963705562718,
+                             -0.08257934547233232460034393423744022769858,
+                             -0.4016954246529694575168416597426171522567,
+                             -0.6772815716257410747621509844956257184155,
+                             -0.8794737512064890713908547548818411172079,
+                             -0.9863613034027223736025091948190671107285 };
+        return t[k];
+    }
+    static FA_DEV double s(int k) {
+        const double t[] = { 0.0,
+                             0.3246994692046834874075727165465870379355,
+                             0.6142127126896678174443358335144494567519,
+                             0.8371664782625285748060612009369102474987,
+                             0.9694002659393304167361073217961682259573,
+                             0.9965844930066698498193520007504877187805,
+                             0.9157733266550574399193492356940089700767,
+                             0.7357239106731316247742076119610924993214,
+                             0.4759473930370735444313529194551153377644,
+                             0.1645945902807338941436520590879384195122 };
+        return t[k];
+    }
+};
+template <> struct Bfly<19> : BflyOdd<19> {};
+template <> struct OddTrig<23> {
+    static FA_DEV double c(int k) {
+        const double t[] = { 1.0,
+                             0.962917287347799295015223597373238799355,
+                             0.8544194045464885525482156195502508000479,
+                             0.6825531432186540828745375453725405780988,
+                             0.4600650377311521260415757598109517955579,
+                             0.2034560130526337898780287220615784267778,
+                             -0.06824241336467097592118847902245902393309,
+                             -0.3348796121709861519581150708478901575074,
+                             -0.5766803221148671412510482752668528239789,
+                             -0.7757112907044198070411010109695368955877,
+                             -0.9172113015054530178438054479656154936903,
+                             -0.99068594603633075234232296009620600514 };
+        return t[k];
+    }
+    static FA_DEV double s(int k) {
+        const double t[] = { 0.0,
+                             0.2697967711570242712453285226025705364753,
+                             0.5195839500354335781330010113237876331493,
+                             0.7308359642781241016508331160835884644009,
+                             0.8878852184023752349842692774195844835989,
+                             0.9790840876823228756328148847602371349847,
+                             0.9976687691905391984535782806992783166368,
+                             0.9422609221188204956176842253179721336254,
+                             0.8169698930104420169734140372449881772468,
+                             0.6310879443260527893674001301433105742008,
+                             0.39840108984624145799788039996967896565,
+                             0.1361666490962465907607258333878729914504 };
+        return t[k];
+    }
+};
+template <> struct Bfly<23> : BflyOdd<23> {};
+
 #endif /* FA_BUTTERFLIES_H */
