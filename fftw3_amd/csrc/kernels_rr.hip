@@ -117,13 +117,13 @@ static void launch_3s(const P3SArgs &pa, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((pass3s_kernel<R1>), grid, dim3(256), lds, st, pa);
 }
 
-/* contiguous rows of 2048 / 4096 in one pass; 1 = not applicable */
+/* contiguous rows of 2048 / 4096 / 8192 in one pass; 1 = not applicable */
 int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                      i64 cs, i64 cn, hipStream_t st) {
     P3SArgs pa;
     int bd = d->batch_dim, T;
     i64 sbase = d->src_base, dbase = d->dst_base;
-    if ((d->L != 2048 && d->L != 4096) || d->src_im != 1 || d->dst_im != 1 || d->tw_n ||
+    if ((d->L != 2048 && d->L != 4096 && d->L != 8192) || d->src_im != 1 || d->dst_im != 1 || d->tw_n ||
         d->is_l != 2 || d->os_l != 2 || d->tile_lo_n > 1 ||
         (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
         return 1;
@@ -153,7 +153,8 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
     if (nblocks > 0x7fffffffLL) return 1;
     dim3 grid((unsigned)nblocks, 1, 1);
     if (d->L == 2048) launch_3s<8>(pa, grid, st);
-    else launch_3s<16>(pa, grid, st);
+    else if (d->L == 4096) launch_3s<16>(pa, grid, st);
+    else launch_3s<32>(pa, grid, st);
     return 0;
 }
 

@@ -1,6 +1,6 @@
 /*
  * pass3s.hpp -- register-resident three-stage pass for contiguous rows of
- * L = 2048 (8 x 16 x 16) or 4096 (16 x 16 x 16).
+ * L = 2048 (8 x 16 x 16), 4096 (16 x 16 x 16) or 8192 (32 x 16 x 16, one row per tile).
  *
  * One workgroup (256 work-items) transforms T = 8192 / L whole rows; every
  * work-item keeps 32 elements in registers through three radix stages and two

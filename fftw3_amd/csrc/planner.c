@@ -450,7 +450,7 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
             s->variant = FFTW_AMD_K_P1024;  /* register-resident radix-32x32, 8 sequences per tile */
             s->tile = 8;
         } else if (fa_hip_r3_tile((int)L) > 0 && is_l == 2 && os_l == 2 && tw_n == 0 && s->tile_lo_n == 1 &&
-                   (L == 2048 || L == 4096 || s->dim_n[0] * 2 >= fa_hip_r3_tile((int)L))) {
+                   (L == 2048 || L == 4096 || L == 8192 || s->dim_n[0] * 2 >= fa_hip_r3_tile((int)L))) {
             s->variant = FFTW_AMD_K_R3;     /* three-stage register kernel, whole contiguous rows */
             s->tile = fa_hip_r3_tile((int)L);
         } else if (fa_hip_rr_tile((int)L) > 0 && s->dim_n[0] * s->tile_lo_n * 4 >= fa_hip_rr_tile((int)L) &&
@@ -894,6 +894,31 @@ static void mixed_two_pass_split(i64 n, i64 *lens) {
     }
 }
 
+static int rows_alias_ok(const plan *p, const fa_axis *ax, fa_loc a, fa_loc b);
+
+/* May a contiguous axis longer than FA_LMAX_SINGLE run as ONE trip of a register rows kernel?  Such a step has
+   no LDS-kernel fallback (the row does not fit the runtime-radix kernel), so everything the rows kernel needs is
+   settled here, at plan time: interleaved unit-stride rows, 16-byte aligned user arrays and even loop strides,
+   rows that map onto themselves when the transform is in place, no two-level tile dim, no FFTW_UNALIGNED. */
+static int long_rows_ok(const plan *p, const fa_axis *ax) {
+    int j, rows = 0;
+    if (ax->is != 2 || ax->os != 2 || ax->src.im != 1 || ax->dst.im != 1) return 0;
+    if ((ax->flags_in | ax->flags_out) & ~(FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT)) return 0;
+    if (!rows_alias_ok(p, ax, ax->src, ax->dst)) return 0;
+    for (j = 0; j < ax->nloops; ++j) {
+        if ((ax->loops[j].is % 2) || (ax->loops[j].os % 2)) return 0;
+        if (ax->loops[j].n == 2 && (iabs(ax->loops[j].is) == 2 || iabs(ax->loops[j].os) == 2)) return 0;
+        if (ax->loops[j].n > 1) rows = 1;
+    }
+    if (!rows) return 0;
+    if ((ax->src.base % 2) || (ax->dst.base % 2)) return 0;
+    if (ax->src.buf == 0 && ((size_t)p->ri % 16)) return 0;
+    if (ax->src.buf == 1 && ((size_t)p->ro % 16)) return 0;
+    if (ax->dst.buf == 0 && ((size_t)p->ri % 16)) return 0;
+    if (ax->dst.buf == 1 && ((size_t)p->ro % 16)) return 0;
+    return 1;
+}
+
 static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     fa_axis ax = *ax_in;
     i64 lens[FA_MAXPASS];
@@ -929,7 +954,10 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
                      ax.src.im == 1 && ax.dst.im == 1 &&
                      !((ax.flags_in | ax.flags_out) & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT)) &&
                      !getenv("FFTW_AMD_NO_3S");
+        /* 8192: one row per workgroup (32 x 16 x 16), one trip instead of 128 x 64 in two */
+        if (rows3s && ax.n > FA_LMAX_SINGLE) rows3s = long_rows_ok(p, &ax);
         if (!rows3s) lmax1 = 1024;
+        else if (ax.n > lmax1) lmax1 = ax.n;
     }
     if (ax.nloops == 0 && !contiguous) lmax1 = FA_LMAX_SINGLE;
     /* 1024 < n <= 4096 that is not a power of two: two register-kernel passes (each near

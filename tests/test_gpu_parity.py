@@ -201,6 +201,52 @@ def test_register_kernels_wide_batches(torch_dev, n):
     assert aerror(y, oracle_dft(x, (n,), 9).reshape(9, n)) < TOL
 
 
+def test_rows_of_8192_in_one_trip(torch_dev):
+    """contiguous interleaved rows of 8192 points: one workgroup per row (32 x 16 x 16, pass3s.hpp), a step
+    without an LDS-kernel fallback -- so plans that cannot promise its layout at plan time (FFTW_UNALIGNED,
+    a lone transform) keep the two-pass split; both compute the same answer"""
+    torch, dev = torch_dev
+    n = 8192
+    rng = np.random.default_rng(8192)
+    for b, sign in ((77, -1), (3, 1)):
+        x = crand(rng, b, n)
+        dx = torch.from_numpy(x).to(dev)
+        dy = torch.zeros_like(dx)
+        p = fa.plan_many_dft(1, [n], b, dx, None, 1, n, dy, None, 1, n, sign)
+        assert "pass-8192/reg3" in p.sprint() and len(p.steps()) == 1, p.sprint()
+        p.execute()
+        p.sync()
+        ref = oracle_dft(x, (n,), b, sign).reshape(b, n)
+        assert aerror(dy.cpu().numpy(), ref) < TOL
+        q = fa.plan_many_dft(1, [n], b, dx, None, 1, n, dy, None, 1, n, sign, fa.ESTIMATE | fa.UNALIGNED)
+        assert len(q.steps()) == 2, q.sprint()
+        dy.zero_()
+        q.execute()
+        q.sync()
+        assert aerror(dy.cpu().numpy(), ref) < TOL
+        # in place: every row maps onto itself
+        r = fa.plan_many_dft(1, [n], b, dx, None, 1, n, dx, None, 1, n, sign)
+        assert len(r.steps()) == 1, r.sprint()
+        r.execute()
+        r.sync()
+        assert aerror(dx.cpu().numpy(), ref) < TOL
+    # padded rows (idist > n) and the rows axis of a 2-D transform
+    x = crand(rng, 5, n + 6)
+    dx = torch.from_numpy(x).to(dev)
+    dy = torch.zeros(5, n + 2, dtype=torch.complex128, device=dev)
+    p = fa.plan_many_dft(1, [n], 5, dx, None, 1, n + 6, dy, None, 1, n + 2, fa.FORWARD)
+    assert "pass-8192/reg3" in p.sprint(), p.sprint()
+    p.execute()
+    p.sync()
+    assert aerror(dy.cpu().numpy()[:, :n], oracle_dft(np.ascontiguousarray(x[:, :n]), (n,), 5).reshape(5, n)) < TOL
+    assert float(dy[:, n:].abs().max()) == 0.0
+    x = crand(rng, 1, 12 * n)
+    y = gpu_c2c(torch_dev, x, (12, n), 1)
+    assert aerror(y, oracle_dft(x, (12, n), 1).reshape(1, 12 * n)) < TOL
+    one = fa.plan_dft_1d(n, dx, dy, fa.FORWARD)
+    assert len(one.steps()) == 2, one.sprint()
+
+
 @pytest.mark.parametrize("k,lens", [(22, [128, 128, 256]), (23, [128, 128, 512]), (24, [128, 128, 1024]),
                                     (25, [512, 128, 512])])
 def test_three_pass_powers_of_two(torch_dev, k, lens):

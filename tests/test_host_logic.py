@@ -27,7 +27,7 @@ def _c2c(n, b, sign, inplace=False):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 16, 17, 25, 31, 32, 61, 64, 77,
-                               97, 100, 143, 1009, 1024, 1031, 4096, 5000, 15015, 17408, 65536])
+                               97, 100, 143, 1009, 1024, 1031, 4096, 5000, 8192, 15015, 17408, 65536])
 def test_planner_c2c_1d(n):
     for b in (1, 3):
         for sign in (-1, 1):
