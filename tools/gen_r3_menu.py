@@ -7,7 +7,8 @@ balanced factorisations are compiled for gfx950 in every order and the one with 
 fewest spilled VGPRs (then the most rows per tile) wins.  Writes
 fftw3_amd/csrc/r3_menu.inc (committed; the library build never runs this search).
 
-usage: python tools/gen_r3_menu.py   (needs hipcc; a few minutes on 8 cores)
+usage: python tools/gen_r3_menu.py            (needs hipcc; a few minutes on 8 cores)
+       python tools/gen_r3_menu.py --extend   keep the menu, add 13-smooth lengths and the lengths in (4096, 8192]
 """
 import itertools
 import os
@@ -93,7 +94,69 @@ def fits_t(r1, r2, r3):
     return t >= 4 and q(t * r2 * r3) * r1 <= 40 and q(t * r1 * r3) * r2 <= 40 and q(t * r1 * r2) * r3 <= 40
 
 
+RADICES_WIDE = [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 21, 22, 24, 25, 26, 27, 28, 30, 32]
+
+
+def smooth13(n):
+    for p in (2, 3, 5, 7, 11, 13):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
+def extend():
+    """--extend: keep every entry of r3_menu.inc and add (a) the 13-smooth lengths in (512, 4096] that have neither
+    a two-stage nor a three-stage kernel yet and (b) the lengths in (4096, 8192] (one row per workgroup), over the
+    wider radix set; per length the two most balanced factorisations, outer radices as equal as possible.  The
+    strided menu (r3t_menu.inc) is not touched."""
+    have2 = rr_menu()
+    path = os.path.join(CSRC, "r3_menu.inc")
+    with open(path) as f:
+        old = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read())]
+    have3 = set(e[0] for e in old)
+    cands = []
+    for L in range(513, 8193):
+        if not smooth13(L) or L & (L - 1) == 0 or L in have2 or L in have3:
+            continue
+        facts = set()
+        for a in RADICES_WIDE:
+            for b in RADICES_WIDE:
+                if L % (a * b) == 0 and (L // (a * b)) in RADICES_WIDE and a <= b <= L // (a * b):
+                    facts.add((a, b, L // (a * b)))
+        for f in sorted(facts, key=lambda f: f[2] / f[0])[:2]:
+            perms = sorted((p for p in set(itertools.permutations(f)) if fits(*p)),
+                           key=lambda p: (abs(p[0] - p[2]), p[0] > p[2]))
+            cands.extend(perms[:2])
+    cands = sorted(set(cands))
+    print("%d candidate kernels" % len(cands), file=sys.stderr)
+    nproc = 8
+    spills = {}
+    # small compilation units: a translation unit of 100 big kernels takes minutes
+    units = [cands[i:i + 12] for i in range(0, len(cands), 12)]
+    with ThreadPoolExecutor(nproc) as ex:
+        for r in ex.map(lambda t: compile_triples(*t), enumerate(units)):
+            spills.update(r)
+    best = {}
+    for (a, b, c), s in sorted(spills.items()):
+        L = a * b * c
+        if s > MAX_SPILL:
+            continue
+        key = (s, -tile(a, b, c), abs(a - c))
+        if L not in best or key < best[L][3]:
+            best[L] = (a, b, c, key)
+    rows = dict((e[0], e[1:]) for e in old)
+    for L in best:
+        rows[L] = best[L][:3]
+    with open(path, "w") as f:
+        f.write("/* generated by tools/gen_r3_menu.py -- X(L, R1, R2, R3): three-stage rows kernel of length L */\n")
+        for L in sorted(rows):
+            f.write("X(%d, %d, %d, %d)\n" % ((L,) + tuple(rows[L])))
+    print("%d new lengths, %d in all" % (len(best), len(rows)), file=sys.stderr)
+
+
 def main():
+    if "--extend" in sys.argv:
+        return extend()
     have2 = rr_menu()
     cands = []
     for L in range(513, 4097):
