@@ -505,4 +505,86 @@ template <> struct OddTrig<23> {
 };
 template <> struct Bfly<23> : BflyOdd<23> {};
 
+/* 29 and 31: only the one-stage rows kernel (pass1r.hpp) uses them */
+template <> struct OddTrig<29> {
+    static FA_DEV double c(int k) {
+        const double t[] = { 1.0,
+                             0.976620555710086683208227962877863351799,
+                             0.9075754196709570536201612900285178073502,
+                             0.7960930657056437459980762465098682421823,
+                             0.6473862847818276391816601341861462687573,
+                             0.4684084406997901392162396741494573562814,
+                             0.2675283385292208211946262052833413401837,
+                             0.05413890858541752614990832597459869261258,
+                             -0.1617819965527647265442600643364213138442,
+                             -0.370138155339914356863980667615164457098,
+                             -0.5611870653623823692699409283736092029758,
+                             -0.7259954919231308581383348989285119089043,
+                             -0.8568571761675892445230765519053744460274,
+                             -0.9476531711828024442740040119711601634623,
+                             -0.9941379571543596089553027158795515668546 };
+        return t[k];
+    }
+    static FA_DEV double s(int k) {
+        const double t[] = { 0.0,
+                             0.2149704402110240671819534770820757537978,
+                             0.4198891015602645769737108950291563357024,
+                             0.6051742151937651659242801329801084792646,
+                             0.7621620551276364632557304138001066169968,
+                             0.8835120444460229228273168942218641218896,
+                             0.9635499925192229600433361810024919509632,
+                             0.9985334138511238645717905110783489569243,
+                             0.9868265225415261517686243504388935079839,
+                             0.9289767198167914417896296010855542620842,
+                             0.8276889981568905561357816231375032629305,
+                             0.6876994588534232930838768523753670644636,
+                             0.5155538571770217397098664966397134305305,
+                             0.3193015301359799731972335422795273269787,
+                             0.1081190184239417630308083269836870058627 };
+        return t[k];
+    }
+};
+template <> struct Bfly<29> : BflyOdd<29> {};
+template <> struct OddTrig<31> {
+    static FA_DEV double c(int k) {
+        const double t[] = { 1.0,
+                             0.9795299412524944939380064428117707242914,
+                             0.9189578116202306291271881732781545512765,
+                             0.8207634412072763263635445613553707767235,
+                             0.68896691907568656780086680381814168713,
+                             0.5289640103269624573654923939122347256678,
+                             0.347305252844820285541854355481012246462,
+                             0.1514277775045766636574676467272196523058,
+                             -0.05064916883871271227875185748519952674658,
+                             -0.2506525322587205393148020352659594949329,
+                             -0.4403941515576343095161715337137760630174,
+                             -0.6121059825476628441467056202598600662487,
+                             -0.7587581226927909019132546363634371874187,
+                             -0.8743466161445821188274846642006517855751,
+                             -0.9541392564000488514758967202113007469136,
+                             -0.994869323391895146321353309883719493004 };
+        return t[k];
+    }
+    static FA_DEV double s(int k) {
+        const double t[] = { 0.0,
+                             0.2012985200886600791415289683390134818534,
+                             0.3943558551133185801016261030214455736356,
+                             0.5712682150947922791574245436284554823535,
+                             0.7247927872291199588654846624405482525919,
+                             0.8486442574947509504641043389938084539826,
+                             0.9377521321470804584291761743123298881309,
+                             0.988468324328111399162190689403153774921,
+                             0.9987165071710528071463114367595140457475,
+                             0.9680771188662043051530076728012907428348,
+                             0.8978045395707416571368028976620412024435,
+                             0.7907757369376985820782204594612615906186,
+                             0.651372482722222207453999614691016466092,
+                             0.4853019625310810252145722292597299794313,
+                             0.2993631229733579540081126169766754622405,
+                             0.1011683219874321777860407155854228233862 };
+        return t[k];
+    }
+};
+template <> struct Bfly<31> : BflyOdd<31> {};
+
 #endif /* FA_BUTTERFLIES_H */

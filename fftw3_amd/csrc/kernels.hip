@@ -1135,6 +1135,9 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
                      i64 cs, i64 cn, hipStream_t st);
 int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                      i64 cs, i64 cn, hipStream_t st);
+/* kernels_r1.hip */
+int fa_launch_pass1r(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                     i64 cs, i64 cn, hipStream_t st);
 
 template <bool IN_T, bool OUT_T, int HAS_TW>
 static void launch_p1024_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
@@ -1296,6 +1299,7 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
     PassArgs pa;
     if (d->flags & (FFTW_AMD_F_R2C_ROWS | FFTW_AMD_F_C2R_ROWS)) return fa_launch_r2crows(d, bufs, tables, cs, cn, st);
     if (d->variant == FFTW_AMD_K_P1024 && launch_p1024(d, bufs, tables, cs, cn, st) == 0) return 0;
+    if (d->variant == FFTW_AMD_K_R1 && fa_launch_pass1r(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_RR && fa_launch_passrr(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_R3 && (fa_launch_pass3s(d, bufs, tables, cs, cn, st) == 0 ||
                                         fa_launch_pass3g(d, bufs, tables, cs, cn, st) == 0 ||

@@ -449,6 +449,10 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
         if (L == 1024) {
             s->variant = FFTW_AMD_K_P1024;  /* register-resident radix-32x32, 8 sequences per tile */
             s->tile = 8;
+        } else if (L <= 32 && fa_hip_r1_tile((int)L) > 0 && is_l == 2 && os_l == 2 && tw_n == 0 && s->tile_lo_n == 1 &&
+                   s->dim_is[0] == 2 * L && s->dim_os[0] == 2 * L && s->dim_n[0] >= 256 && !getenv("FFTW_AMD_NO_R1")) {
+            s->variant = FFTW_AMD_K_R1;     /* dense rows of a short length: one butterfly per row (pass1r.hpp) */
+            s->tile = fa_hip_r1_tile((int)L);
         } else if (fa_hip_r3_tile((int)L) > 0 && is_l == 2 && os_l == 2 && tw_n == 0 && s->tile_lo_n == 1 &&
                    (L == 2048 || L == 4096 || L == 8192 || s->dim_n[0] * 2 >= fa_hip_r3_tile((int)L))) {
             s->variant = FFTW_AMD_K_R3;     /* three-stage register kernel, whole contiguous rows */
@@ -2458,6 +2462,7 @@ char *fa_sprint(const plan *p) {
             else if (d->variant == FFTW_AMD_K_P1024) sapp(s, cap, &len, "reg32x32");
             else if (d->variant == FFTW_AMD_K_RR) sapp(s, cap, &len, "reg2");
             else if (d->variant == FFTW_AMD_K_R3) sapp(s, cap, &len, "reg3");
+            else if (d->variant == FFTW_AMD_K_R1) sapp(s, cap, &len, "reg1");
             else {
                 sapp(s, cap, &len, "lds:");
                 for (j = 0; j < d->nradices; ++j)

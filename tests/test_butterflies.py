@@ -31,7 +31,7 @@ extern "C" int bfly(int r, double *d) {
     case 20: run<20>(d); break; case 24: run<24>(d); break; case 25: run<25>(d); break;
     case 18: run<18>(d); break; case 21: run<21>(d); break; case 22: run<22>(d); break;
     case 26: run<26>(d); break; case 27: run<27>(d); break; case 28: run<28>(d); break;
-    case 30: run<30>(d); break; case 17: run<17>(d); break; case 19: run<19>(d); break; case 23: run<23>(d); break;
+    case 30: run<30>(d); break; case 17: run<17>(d); break; case 19: run<19>(d); break; case 23: run<23>(d); break; case 29: run<29>(d); break; case 31: run<31>(d); break;
     default: return -1;
     }
     return 0;
@@ -49,7 +49,7 @@ def test_butterflies_match_dft():
         lib = C.CDLL(so)
         lib.bfly.argtypes = [C.c_int, C.c_void_p]
         rng = np.random.default_rng(0)
-        for r in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30):
+        for r in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31):
             for _ in range(3):
                 x = rng.random(r) - 0.5 + 1j * (rng.random(r) - 0.5)
                 d = x.copy()

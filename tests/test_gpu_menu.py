@@ -163,3 +163,38 @@ def test_three_stage_strided_forms(L, r1, r2, r3, monkeypatch):
     p, e = _run(512 * L, 4, 1, 512 * L)
     assert "pass-%d/reg3" % L in p.sprint(), p.sprint()
     assert e <= TOL, (L, e)
+
+
+@pytest.mark.parametrize("L", list(range(2, 33)))
+def test_one_stage_rows_kernel(L, monkeypatch):
+    """dense rows of 2 ... 32 points, one butterfly per row (pass1r.hpp): a batch that ends inside a tile and one that
+    ends inside the first 256-element run of a tile, forward out of place and backward in place, against the oracle;
+    rows that are not dense (idist > n) and the FFTW_AMD_NO_R1 hook take the other kernels and agree"""
+    import torch
+    tile = 256 * (6 if L == 4 else min(8, 32 // L))
+    for hm in (2 * tile + 257, tile + 3):
+        p, e = _run(L, hm, 1, L)
+        assert "pass-%d/reg1" % L in p.sprint(), p.sprint()
+        assert e <= TOL, (L, hm, e)
+    hm = tile + 300
+    rng = np.random.default_rng(L)
+    x = crand(rng, hm * L)
+    xd = torch.from_numpy(x).cuda()
+    q = fa.plan_many_dft(1, [L], hm, xd, None, 1, L, xd, None, 1, L, fa.BACKWARD)
+    assert "pass-%d/reg1" % L in q.sprint()
+    q.execute()
+    q.sync()
+    assert aerror(xd.cpu().numpy(), oracle_dft(x, (L,), hm, sign=+1)) <= TOL, L
+    x = crand(rng, 300 * (L + 1))
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros_like(xd)
+    p = fa.plan_many_dft(1, [L], 300, xd, None, 1, L + 1, yd, None, 1, L + 1, fa.FORWARD)
+    assert "reg1" not in p.sprint(), p.sprint()
+    p.execute()
+    p.sync()
+    want = oracle_dft(np.ascontiguousarray(x.reshape(300, L + 1)[:, :L]), (L,), 300).reshape(300, L)
+    got = yd.cpu().numpy().reshape(300, L + 1)
+    assert aerror(got[:, :L], want) <= TOL and np.all(got[:, L] == 0), L
+    monkeypatch.setenv("FFTW_AMD_NO_R1", "1")
+    p, e = _run(L, hm, 1, L)
+    assert "reg1" not in p.sprint() and e <= TOL, (L, e)
