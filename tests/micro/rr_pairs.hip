@@ -16,13 +16,13 @@ static cplx *g_w;
 static hipStream_t g_st;
 
 template <int R1, int R2, bool IN_T, bool OUT_T>
-static double time_form() {
+static double time_form(int flags = 0) {
     typedef RRGeom<R1, R2> G;
     constexpr int L = R1 * R2, T = G::T;
     P1024Args a;
     memset((void *)&a, 0, sizeof(a));
     for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) a.dn[i] = 1;
-    a.src = g_in; a.dst = g_out; a.w1024 = g_w;
+    a.src = g_in; a.dst = g_out; a.w1024 = g_w; a.flags = flags;
     if (!IN_T) {                       /* dense rows */
         a.ndims = 1;
         a.dn[0] = NELEM / L; a.dis[0] = a.dos[0] = 2 * L; a.is_l = a.os_l = 2;
@@ -56,8 +56,10 @@ template <int R1, int R2> static void run_pair() {
     const double gb = 32.0 * (NELEM / (R1 * R2)) * (R1 * R2) / 1e9;
     double tr = time_form<R1, R2, false, false>();
     double tc = time_form<R1, R2, true, true>();
-    printf("L=%-4d %2d x %-2d tile=%-4d wgs=%d  rows %6.3f ms %5.2f TB/s   cols %6.3f ms %5.2f TB/s\n", R1 * R2, R1, R2, G::T,
-           fa_rr_wgs(R1, R2), tr, gb / tr, tc, gb / tc);
+    double tri = time_form<R1, R2, false, false>(FFTW_AMD_F_NT_IN), tro = time_form<R1, R2, false, false>(FFTW_AMD_F_NT_OUT);
+    double tcb = time_form<R1, R2, true, true>(FFTW_AMD_F_NT_IN | FFTW_AMD_F_NT_OUT);
+    printf("L=%-4d %2d x %-2d tile=%-4d wgs=%d  rows %5.2f TB/s (nt-in %5.2f, nt-out %5.2f)   cols %5.2f TB/s (nt %5.2f)\n", R1 * R2, R1, R2, G::T,
+           fa_rr_wgs(R1, R2), gb / tr, gb / tri, gb / tro, gb / tc, gb / tcb);
     fflush(stdout);
 }
 
