@@ -203,8 +203,15 @@ extern "C" int fa_hip_r2c_rows_tile(int L) {
 /* A step with FFTW_AMD_F_R2C_ROWS / FFTW_AMD_F_C2R_ROWS has no other executor: the planner only emits it for
    layouts this kernel takes (r2c_rows_layout_ok), so anything else here is a caller error
    (new-array execution with differently aligned arrays) and fails loudly. */
+extern "C" int fa_hip_r2c_rows3_tile(int L);
+int fa_launch_r2crows3(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                       i64 cs, i64 cn, hipStream_t st);
+
 int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                       i64 cs, i64 cn, hipStream_t st) {
+    /* half lengths above 1024: the three-stage form (kernels_rr.hip) */
+    if (fa_hip_r2c_rows_tile(d->L) <= 0 && fa_hip_r2c_rows3_tile(d->L) > 0)
+        return fa_launch_r2crows3(d, bufs, tables, cs, cn, st);
     R2CRArgs ra;
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;

@@ -180,6 +180,83 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
     return 0;
 }
 
+/* rows per tile of the fused real-rows form of the three-stage kernel (half length L; plain r2c / c2r without
+   r2r hooks), 0: none */
+extern "C" int fa_hip_r2c_rows3_tile(int L) {
+    return (L == 2048 || L == 4096 || L == 8192) ? 8192 / L : 0;
+}
+
+template <int R1>
+static void launch_3s_real(const P3SArgs &pa, dim3 grid, hipStream_t st, bool inverse) {
+    static std::atomic<unsigned> attr_done{0};
+    const size_t lds = P3SGeom<R1>::lds_doubles * sizeof(double);
+    if (fa_attr_needed(attr_done)) {
+        FA_CHECK(hipFuncSetAttribute((const void *)pass3s_kernel<R1, 1>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass3s_kernel<R1, 2>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        fa_attr_set(attr_done);
+    }
+    if (inverse) hipLaunchKernelGGL((pass3s_kernel<R1, 2>), grid, dim3(256), lds, st, pa);
+    else hipLaunchKernelGGL((pass3s_kernel<R1, 1>), grid, dim3(256), lds, st, pa);
+}
+
+/* real rows of n = 2L <-> half spectra in one trip, L = 2048 / 4096 / 8192 (pass3s_kernel MODE 1 / 2).  Like the
+   two-stage form (fa_launch_r2crows) the step has no other executor: a layout the planner did not promise is a
+   caller error (new-array execution with differently aligned arrays) and fails loudly. */
+int fa_launch_r2crows3(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                       i64 cs, i64 cn, hipStream_t st) {
+    P3SArgs pa;
+    int bd = d->batch_dim;
+    i64 sbase = d->src_base, dbase = d->dst_base;
+    const int T = fa_hip_r2c_rows3_tile(d->L);
+    const bool inverse = (d->flags & FFTW_AMD_F_C2R_ROWS) != 0;
+    if (T <= 0 || d->tile != T || d->src_im != 1 || d->dst_im != 1 || d->is_l != 2 || d->os_l != 2 ||
+        d->aux_valid || d->aux_buf > 0 || d->tile_lo_n > 1) {
+        fprintf(stderr, "fftw3_amd: internal error: fused r2c rows step with an unsupported layout\n");
+        abort();
+    }
+    for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
+        pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
+        pa.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
+        pa.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
+    }
+    if (bd >= 0) {
+        sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
+        dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
+        pa.dn[bd] = cn;
+    }
+    pa.src = bufs[d->src_buf] + sbase;
+    pa.dst = bufs[d->dst_buf] + dbase;
+    bool odd = ((uintptr_t)pa.src % 16) || ((uintptr_t)pa.dst % 16);
+    for (int i = 0; i < d->ndims; ++i)
+        if ((pa.dis[i] % 2) || (pa.dos[i] % 2)) odd = true;
+    if (odd) {
+        fprintf(stderr, "fftw3_amd: fftw_execute_dft_r2c / _c2r needs arrays aligned like the ones the plan was "
+                        "created with (16 bytes)\n");
+        abort();
+    }
+    pa.wL = (const cplx *)tables[d->table];
+    pa.tw_lo = (const cplx *)tables[d->tw_lo];
+    pa.tw_hi = (const cplx *)tables[d->tw_hi];
+    pa.tw_shift = d->tw_shift;
+    pa.ndims = d->ndims;
+    pa.flags = 0;
+    pa.ntiles = (pa.dn[0] + T - 1) / T;
+    i64 nblocks = pa.ntiles;
+    for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
+    if (nblocks <= 0) return 0;
+    if (nblocks > 0x7fffffffLL) {
+        fprintf(stderr, "fftw3_amd: fused r2c rows step with more than 2^31 tiles\n");
+        abort();
+    }
+    dim3 grid((unsigned)nblocks, 1, 1);
+    if (d->L == 2048) launch_3s_real<8>(pa, grid, st, inverse);
+    else if (d->L == 4096) launch_3s_real<16>(pa, grid, st, inverse);
+    else launch_3s_real<32>(pa, grid, st, inverse);
+    return 0;
+}
+
 /* tile width the register kernels use for a sub-transform length (0: none) */
 extern "C" int fa_hip_rr_tile(int L) {
     switch (L) {

@@ -40,9 +40,24 @@ struct P3SArgs {
     const cplx *wL;
     i64 ntiles;
     int ndims, flags;
+    /* real rows (MODE 1 / 2 of pass3s_kernel): two-level table of w_n^m, n = 2L */
+    const cplx *tw_lo;
+    const cplx *tw_hi;
+    int tw_shift;
 };
 
-template <int R1>
+/* MODE 0: complex rows.
+   MODE 1: real rows of n = 2L -> half spectra of L + 1 entries in ONE trip: the rows are read as the pair sequence
+           z[j] = x[2j] + i x[2j+1] (the same 16-byte loads), and after stage C every item untangles its own
+           outputs, Y[k] = E + w_n^k O with E = (Z[k] + conj Z[L-k]) / 2, O = -i (Z[k] - conj Z[L-k]) / 2
+           (hc2cfdft, fftw/fftw_api.c:5831-5845); the partner Z[L-k] comes through the LDS plane (real parts, then
+           imaginary parts).  The item that owns k = 0 also stores Y[L].
+   MODE 2: the transpose, half spectra -> real rows: stage A builds Z'[l] = E' + i O' from Y[l] and Y[L-l]
+           (E' = Y[l] + conj Y[L-l], O' = (Y[l] - conj Y[L-l]) w_n^-l; both read from global memory, the second run
+           backwards) with real and imaginary part swapped, and stage C stores (Im, Re): the unnormalised backward
+           DFT by the swap identity.
+   Reference: ct_hc2c + hc2cfdft / hc2cbdft, fftw/fftw_api.c:5661-5845; r2crows.hpp is the two-stage form. */
+template <int R1, int MODE = 0>
 __global__ void __launch_bounds__(256, 2)
 pass3s_kernel(const P3SArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
@@ -62,7 +77,21 @@ pass3s_kernel(const P3SArgs a) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const double *p = src + (i64)t * a.dis[0] + 2 * tid;
-        if (t < Tcur) {
+        if (MODE == 2 && t < Tcur) {
+            const double *row = src + (i64)t * a.dis[0];
+            const cplx wb = tw2(a.tw_lo, a.tw_hi, a.tw_shift, tid);
+#pragma unroll
+            for (int i = 0; i < R1; ++i) {
+                const int l = tid + 256 * i;
+                cplx yk = *reinterpret_cast<const cplx *>(row + 2 * l);
+                cplx ym = *reinterpret_cast<const cplx *>(row + 2 * (G::L - l));
+                if (l == 0) { yk.y = 0.0; ym.y = 0.0; }
+                const cplx e = c_make(yk.x + ym.x, yk.y - ym.y);
+                const cplx dd = c_make(yk.x - ym.x, yk.y + ym.y);
+                const cplx o = c_mul(dd, i ? c_mul(wb, tw2(a.tw_lo, a.tw_hi, a.tw_shift, 256 * i)) : wb);
+                x[t][i] = c_make(e.y + o.x, e.x - o.y);              /* (Im Z', Re Z') */
+            }
+        } else if (t < Tcur) {
             ld_run<R1>(x[t], p, 512, (a.flags & FFTW_AMD_F_NT_IN) != 0);
         } else {
 #pragma unroll
@@ -161,9 +190,77 @@ pass3s_kernel(const P3SArgs a) {
 
     /* ---- stage C: DFT-16 over a2, store X[d1 + R1 d2 + 16 R1 c] */
     const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
+    if (MODE == 1) {
+        constexpr int L = G::L;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) RB<16>::run(z[v]);
+        cplx pz[2][16];
+        /* partner of k = kb + 16 R1 c is L - kb - 16 R1 c (one base per butterfly, constant offsets); only k = 0
+           wraps onto itself */
+        int pb[2], p0[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int kb = cd1[v] + R1 * cd2[v];
+            pb[v] = ct[v] * L + L - kb;
+            p0[v] = ct[v] * L + ((L - kb) & (L - 1));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) plane[ct[v] * L + cd1[v] + R1 * cd2[v] + 16 * R1 * c] = z[v][c].x;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                pz[v][c].x = plane[c ? pb[v] - 16 * R1 * c : p0[v]];
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) plane[ct[v] * L + cd1[v] + R1 * cd2[v] + 16 * R1 * c] = z[v][c].y;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                pz[v][c].y = plane[c ? pb[v] - 16 * R1 * c : p0[v]];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int kb = cd1[v] + R1 * cd2[v];
+            const cplx wb = tw2(a.tw_lo, a.tw_hi, a.tw_shift, kb);
+            double *row = dst + (i64)ct[v] * a.dos[0];
+            if (ct[v] < Tcur) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const double ar = z[v][c].x, ai = z[v][c].y, br = pz[v][c].x, bi = pz[v][c].y;
+                    const double er = 0.5 * (ar + br), ei = 0.5 * (ai - bi);
+                    const double dr = 0.5 * (ar - br), di = 0.5 * (ai + bi);
+                    const cplx w = c ? c_mul(wb, tw2(a.tw_lo, a.tw_hi, a.tw_shift, 16 * R1 * c)) : wb;
+                    const cplx q = c_mulc(c_make(di, -dr), w);
+                    cplx yk = c_make(er + q.x, ei + q.y);
+                    if (c == 0 && kb == 0) {
+                        yk.y = 0.0;
+                        *reinterpret_cast<cplx *>(row + 2 * L) = c_make(er - q.x, 0.0);
+                    }
+                    *reinterpret_cast<cplx *>(row + 2 * (kb + 16 * R1 * c)) = yk;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
         RB<16>::run(z[v]);
+        if (MODE == 2) {
+            if (ct[v] < Tcur) {
+                double *p = dst + (i64)ct[v] * a.dos[0] + 2 * (cd1[v] + R1 * cd2[v]);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) *reinterpret_cast<cplx *>(p + (i64)c * (32 * R1)) = c_make(z[v][c].y, z[v][c].x);
+            }
+            continue;
+        }
         if (ct[v] < Tcur) {
             double *p = dst + (i64)ct[v] * a.dos[0] + 2 * (cd1[v] + R1 * cd2[v]);
 #pragma unroll

@@ -1157,6 +1157,13 @@ static int axis_pass_count(i64 n) {
     return k ? k : 99;
 }
 
+/* passes of the half-length complex transform of an r2c / c2r axis: its rows are contiguous, so a length with
+   a three-stage rows kernel (up to 8192) is one pass */
+static int half_axis_pass_count(i64 n) {
+    if (n <= 8192 && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_3S") && fa_hip_r3_tile((int)n) > 0) return 1;
+    return axis_pass_count(n);
+}
+
 /* r2c: last dim real -> half spectrum, then complex DFTs over the other dims
    on the half-spectrum array (reference rank_geq2_rdft2 A.c:10111-10282).
    p->dims[].is are strides of the REAL array (doubles), .os of the complex
@@ -1218,6 +1225,17 @@ static int c2r_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc cur, fa_l
     return 1;
 }
 
+/* rows per tile of the one-trip real-rows kernels for half length `half` (0: none): the two-stage form carries the
+   r2r hooks, the three-stage form (2048 ... 8192) only the plain r2c / c2r */
+static int real_rows_tile(i64 half, int hooks) {
+    int t;
+    if (half > 8192) return 0;
+    t = fa_hip_r2c_rows_tile((int)half);
+    if (t > 0) return t;
+    if (hooks || getenv("FFTW_AMD_NO_3S")) return 0;
+    return fa_hip_r2c_rows3_tile((int)half);
+}
+
 /* can the r2c / c2r axis emitters fuse an r2r epilogue / prologue for this length? */
 static int r2r_can_fuse(i64 nl) { return nl >= 2 && nl % 2 == 0 && !getenv("FFTW_AMD_R2R_UNFUSED"); }
 
@@ -1252,7 +1270,7 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
     int j;
     if (ps == 0) { ps = 2 * rs; pim = rs; }
     if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
-        (axis_pass_count(nl / 4) < axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
+        (axis_pass_count(nl / 4) < half_axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
         /* n = 4m: two complex DFTs of size m on (x[4j], x[4j+1]) and (x[4j+2], x[4j+3]),
            then the radix-4 untangle -- the reference's rdft2-ct-dit/4 + hc2cfdft_4 plan,
            chosen when m needs fewer passes than n/2 (n = 2^22: m = 2^20 is 1024 x 1024) */
@@ -1302,7 +1320,7 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
         buf_release(p, zbuf);
     } else if (nl % 2 == 0 && nl >= 2 && (pre != 0 || (ps == 2 && pim == 1)) &&
                (epi != 0 || (cs == 2 && out.im == 1)) &&
-               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && r2c_rows_layout_ok(p, &ax, in, out, epi, pre)) {
+               real_rows_tile(nl / 2, epi || pre) > 0 && r2c_rows_layout_ok(p, &ax, in, out, epi, pre)) {
         /* contiguous real rows of a supported length: the half-length complex DFT and the
            untangle in ONE trip (r2crows.hpp) instead of a pass plus an untangle step */
         sdim d[FA_MAXLOOPS];
@@ -1318,7 +1336,7 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
         s = &p->steps[p->nsteps - 1];
         s->variant = FFTW_AMD_K_R2C;
         s->aux_buf = pre ? pre : -1;     /* r2r pre-processing gathered inside the row (FFTW_AMD_R2R_PRE_*) */
-        s->tile = fa_hip_r2c_rows_tile((int)(nl / 2));
+        s->tile = real_rows_tile(nl / 2, epi || pre);
         s->tile_lo_n = 1;
         /* aux_n = n, aux_valid = fused r2r epilogue (0: plain half spectrum), aux_base = index
            multiplier of the untangle twiddle in the table (4 with the modulus-4n table of the
@@ -1446,7 +1464,7 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
     int j;
     if (ps == 0) { ps = 2 * rs; pim = rs; }
     if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
-        (axis_pass_count(nl / 4) < axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
+        (axis_pass_count(nl / 4) < half_axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
         /* transpose of the radix-4 r2c plan: tangle into two quarter-length
            spectra, two backward complex DFTs of size m straight into the real array */
         i64 m = nl / 4, zts, lts[FA_MAXLOOPS + 1], total;
@@ -1496,7 +1514,7 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         buf_release(p, zbuf);
     } else if (nl % 2 == 0 && nl >= 2 && (post != 0 || (ps == 2 && pim == 1)) &&
                (pro != 0 || (cs == 2 && cur.im == 1)) &&
-               fa_hip_r2c_rows_tile((int)(nl / 2)) > 0 && c2r_rows_layout_ok(p, &ax, cur, out, pro, post)) {
+               real_rows_tile(nl / 2, pro || post) > 0 && c2r_rows_layout_ok(p, &ax, cur, out, pro, post)) {
         /* contiguous rows of a supported length: tangle + backward half-length DFT in ONE trip */
         sdim d[FA_MAXLOOPS];
         int nd = 0;
@@ -1511,7 +1529,7 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         s = &p->steps[p->nsteps - 1];
         s->variant = FFTW_AMD_K_C2R;
         s->aux_buf = post ? post : -1;   /* r2r output shuffle done by the kernel's store (FFTW_AMD_R2R_POST_E01 / O01) */
-        s->tile = fa_hip_r2c_rows_tile((int)(nl / 2));
+        s->tile = real_rows_tile(nl / 2, pro || post);
         s->tile_lo_n = 1;
         s->aux_n = nl;              /* as in the r2c rows step: n, fused r2r prologue, twiddle multiplier */
         s->aux_valid = pro;

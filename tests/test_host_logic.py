@@ -145,9 +145,11 @@ def test_planner_r2c_inplace_padded_and_nd():
 def test_planner_radix4_real_transforms(monkeypatch):
     """n = 4m: two quarter-length complex DFTs + radix-4 untangle (the reference's
     rdft2-ct-dit/4 + hc2cfdft_4 plan); chosen by itself when m
-    needs fewer passes than n/2 (n = 4096 here, n = 2^22 on the GPU tier), forced for the rest"""
-    x = np.zeros(4096)
-    assert "untangle4" in fa.plan_dft_r2c_1d(4096, x, np.zeros(2049, dtype=complex)).sprint()
+    needs fewer passes than n/2 (n = 2^22: 2^20 = 1024 x 1024 against three passes for 2^21), forced for the rest;
+    a half length with a one-trip rows kernel (2048, 5000 ...) is never beaten"""
+    assert "untangle4" not in fa.plan_dft_r2c_1d(4096, np.zeros(4096), np.zeros(2049, dtype=complex)).sprint()
+    assert "untangle4" not in fa.plan_many_dft_r2c(1, [10000], 8, np.zeros(8), None, 1, 10000, np.zeros(8, dtype=complex), None,
+                                                   1, 5001).sprint()
     assert "untangle4" in fa.plan_dft_r2c_1d(1 << 22, np.zeros(8), np.zeros(8, dtype=complex)).sprint()
     monkeypatch.setenv("FFTW_AMD_FORCE_RADIX4", "1")
     for n in (8, 12, 20, 36, 64, 100, 1000, 4096, 40000):
