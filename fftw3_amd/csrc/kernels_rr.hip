@@ -182,8 +182,11 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
 
 /* rows per tile of the fused real-rows form of the three-stage kernel (half length L; plain r2c / c2r without
    r2r hooks), 0: none */
+extern "C" int fa_hip_r2c_rows3g_tile(int L);     /* kernels_r3r.hip: the mixed-radix lengths of r3r_menu.inc */
+int fa_launch_r2crows3g(int L, const P3SArgs &pa, dim3 grid, hipStream_t st, bool inverse);
 extern "C" int fa_hip_r2c_rows3_tile(int L) {
-    return (L == 2048 || L == 4096 || L == 8192) ? 8192 / L : 0;
+    if (L == 2048 || L == 4096 || L == 8192) return 8192 / L;
+    return fa_hip_r2c_rows3g_tile(L);
 }
 
 template <int R1>
@@ -201,7 +204,8 @@ static void launch_3s_real(const P3SArgs &pa, dim3 grid, hipStream_t st, bool in
     else hipLaunchKernelGGL((pass3s_kernel<R1, 1>), grid, dim3(256), lds, st, pa);
 }
 
-/* real rows of n = 2L <-> half spectra in one trip, L = 2048 / 4096 / 8192 (pass3s_kernel MODE 1 / 2).  Like the
+/* real rows of n = 2L <-> half spectra in one trip, L = 2048 / 4096 / 8192 (pass3s_kernel MODE 1 / 2) and the
+   mixed-radix lengths of r3r_menu.inc (pass3g_kernel MODE 1 / 2, kernels_r3r.hip).  Like the
    two-stage form (fa_launch_r2crows) the step has no other executor: a layout the planner did not promise is a
    caller error (new-array execution with differently aligned arrays) and fails loudly. */
 int fa_launch_r2crows3(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
@@ -253,7 +257,11 @@ int fa_launch_r2crows3(const fftw_amd_step_desc *d, double *const *bufs, void *c
     dim3 grid((unsigned)nblocks, 1, 1);
     if (d->L == 2048) launch_3s_real<8>(pa, grid, st, inverse);
     else if (d->L == 4096) launch_3s_real<16>(pa, grid, st, inverse);
-    else launch_3s_real<32>(pa, grid, st, inverse);
+    else if (d->L == 8192) launch_3s_real<32>(pa, grid, st, inverse);
+    else if (fa_launch_r2crows3g(d->L, pa, grid, st, inverse)) {
+        fprintf(stderr, "fftw3_amd: internal error: no fused real-rows kernel for half length %d\n", d->L);
+        abort();
+    }
     return 0;
 }
 

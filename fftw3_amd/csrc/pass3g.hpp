@@ -57,7 +57,9 @@ template <int R1, int R2, int R3> struct P3GGeom {
     static constexpr int lds_doubles = (E1 > E2 ? E1 : E2) + 16;
 };
 
-template <int R1, int R2, int R3>
+/* MODE 0: complex rows; MODE 1: real rows of n = 2L -> half spectra; MODE 2: half spectra -> real rows -- the
+   fused untangle / tangle of pass3s_kernel (pass3s.hpp) for the general factorisation */
+template <int R1, int R2, int R3, int MODE = 0>
 __global__ void __launch_bounds__(256, 2)
 pass3g_kernel(const P3SArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
@@ -84,7 +86,23 @@ pass3g_kernel(const P3SArgs a) {
         at[u] = g / M;
         aa[u] = g - at[u] * M;
         const double *p = src + (i64)at[u] * a.dis[0] + 2 * aa[u];
-        ld_run<R1>(x[u], p, (i64)(2 * M), (a.flags & FFTW_AMD_F_NT_IN) != 0);
+        if (MODE == 2) {
+            const double *row = src + (i64)at[u] * a.dis[0];
+            const cplx wb = tw2(a.tw_lo, a.tw_hi, a.tw_shift, aa[u]);
+#pragma unroll
+            for (int i = 0; i < R1; ++i) {
+                const int l = aa[u] + M * i;
+                cplx yk = *reinterpret_cast<const cplx *>(row + 2 * l);
+                cplx ym = *reinterpret_cast<const cplx *>(row + 2 * (G::L - l));
+                if (l == 0) { yk.y = 0.0; ym.y = 0.0; }
+                const cplx e = c_make(yk.x + ym.x, yk.y - ym.y);
+                const cplx dd = c_make(yk.x - ym.x, yk.y + ym.y);
+                const cplx o = c_mul(dd, i ? c_mul(wb, tw2(a.tw_lo, a.tw_hi, a.tw_shift, M * i)) : wb);
+                x[u][i] = c_make(e.y + o.x, e.x - o.y);              /* (Im Z', Re Z') */
+            }
+        } else {
+            ld_run<R1>(x[u], p, (i64)(2 * M), (a.flags & FFTW_AMD_F_NT_IN) != 0);
+        }
     }
     if (a.flags & FFTW_AMD_F_SWAP_IN) {
 #pragma unroll
@@ -180,6 +198,63 @@ pass3g_kernel(const P3SArgs a) {
 
     /* ---- stage C: DFT-R3 over a2, store X[d1 + R1 d2 + R1 R2 c] */
     const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
+    if (MODE == 1) {
+        /* every item untangles its own outputs; the partner of k = kb + R1 R2 c is L - kb - R1 R2 c (only k = 0
+           wraps onto itself) and comes through the plane, real parts first */
+        constexpr int L = G::L, KS = R1 * R2;
+#pragma unroll
+        for (int w = 0; w < QC; ++w) RB<R3>::run(z[w]);
+        cplx pz[QC][R3];
+        int pb[QC], p0[QC];
+#pragma unroll
+        for (int w = 0; w < QC; ++w) {
+            const int kb = cd1[w] + R1 * cd2[w];
+            pb[w] = ct[w] * L + L - kb;
+            p0[w] = ct[w] * L + (kb ? L - kb : 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < QC; ++w)
+#pragma unroll
+            for (int c = 0; c < R3; ++c) plane[ct[w] * L + cd1[w] + R1 * cd2[w] + KS * c] = z[w][RB<R3>::slot(c)].x;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < QC; ++w)
+#pragma unroll
+            for (int c = 0; c < R3; ++c) pz[w][c].x = plane[c ? pb[w] - KS * c : p0[w]];
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < QC; ++w)
+#pragma unroll
+            for (int c = 0; c < R3; ++c) plane[ct[w] * L + cd1[w] + R1 * cd2[w] + KS * c] = z[w][RB<R3>::slot(c)].y;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < QC; ++w)
+#pragma unroll
+            for (int c = 0; c < R3; ++c) pz[w][c].y = plane[c ? pb[w] - KS * c : p0[w]];
+#pragma unroll
+        for (int w = 0; w < QC; ++w) {
+            const int kb = cd1[w] + R1 * cd2[w];
+            const cplx wb = tw2(a.tw_lo, a.tw_hi, a.tw_shift, kb);
+            double *row = dst + (i64)ct[w] * a.dos[0];
+#pragma unroll
+            for (int c = 0; c < R3; ++c) {
+                const cplx zk = z[w][RB<R3>::slot(c)];
+                const double ar = zk.x, ai = zk.y, br = pz[w][c].x, bi = pz[w][c].y;
+                const double er = 0.5 * (ar + br), ei = 0.5 * (ai - bi);
+                const double dr = 0.5 * (ar - br), di = 0.5 * (ai + bi);
+                const cplx tw = c ? c_mul(wb, tw2(a.tw_lo, a.tw_hi, a.tw_shift, KS * c)) : wb;
+                const cplx q = c_mulc(c_make(di, -dr), tw);
+                cplx yk = c_make(er + q.x, ei + q.y);
+                if (c == 0 && kb == 0) {
+                    yk.y = 0.0;
+                    *reinterpret_cast<cplx *>(row + 2 * L) = c_make(er - q.x, 0.0);
+                }
+                *reinterpret_cast<cplx *>(row + 2 * (kb + KS * c)) = yk;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int w = 0; w < QC; ++w) {
         RB<R3>::run(z[w]);
@@ -187,6 +262,7 @@ pass3g_kernel(const P3SArgs a) {
 #pragma unroll
         for (int c = 0; c < R3; ++c) {
             cplx v = z[w][RB<R3>::slot(c)];
+            if (MODE == 2) { *reinterpret_cast<cplx *>(p + (i64)c * (2 * R1 * R2)) = c_make(v.y, v.x); continue; }
             if (sw) { double s = v.x; v.x = v.y; v.y = s; }
             st_sel(p + (i64)c * (2 * R1 * R2), v, (a.flags & FFTW_AMD_F_NT_OUT) != 0);
         }

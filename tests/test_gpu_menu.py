@@ -200,3 +200,58 @@ def test_one_stage_rows_kernel(L, monkeypatch):
     monkeypatch.setenv("FFTW_AMD_NO_R1", "1")
     p, e = _run(L, hm, 1, L)
     assert "reg1" not in p.sprint() and e <= TOL, (L, e)
+
+
+def menu3r():
+    out = []
+    with open(os.path.join(ROOT, "fftw3_amd", "csrc", "r3r_menu.inc")) as f:
+        for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read()):
+            out.append(tuple(int(v) for v in m.groups()))
+    return out
+
+
+MENU3R = menu3r()
+
+
+@pytest.mark.parametrize("L,r1,r2,r3", MENU3R + [(2048, 8, 16, 16), (4096, 16, 16, 16), (8192, 32, 16, 16)],
+                         ids=[str(m[0]) for m in MENU3R] + ["2048", "4096", "8192"])
+def test_three_stage_real_rows(L, r1, r2, r3):
+    """real rows of n = 2L in one trip (pass3g / pass3s MODE 1, 2): r2c with a ragged last tile against the oracle, c2r of
+    the result (out of place: input preserved; then in FFTW's padded in-place layout) against n x"""
+    import torch
+    from util import oracle_r2c, oracle_c2r, rrand
+    assert r1 * r2 * r3 == L
+    n, hm = 2 * L, 11
+    rng = np.random.default_rng(L)
+    x = rrand(rng, hm, n)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros((hm, L + 1), dtype=torch.complex128, device="cuda")
+    p = fa.plan_many_dft_r2c(1, [n], hm, xd, None, 1, n, yd, None, 1, L + 1)
+    assert "pass-%d/r2c-rows" % L in p.sprint() and len(p.steps()) == 1, p.sprint()
+    p.execute()
+    p.sync()
+    want = oracle_r2c(x, (n,), hm).reshape(hm, L + 1)
+    assert aerror(yd.cpu().numpy(), want) <= TOL, L
+    y = yd.cpu().numpy().copy()
+    zd = torch.zeros((hm, n), dtype=torch.float64, device="cuda")
+    q = fa.plan_many_dft_c2r(1, [n], hm, yd, None, 1, L + 1, zd, None, 1, n)
+    assert "pass-%d/c2r-rows" % L in q.sprint() and len(q.steps()) == 1, q.sprint()
+    q.execute()
+    q.sync()
+    assert aerror(zd.cpu().numpy().reshape(-1), oracle_c2r(want.reshape(-1), (n,), hm)) <= TOL, L
+    assert np.array_equal(yd.cpu().numpy(), y)
+    # in place, rows padded to 2 (L + 1) reals
+    buf = np.zeros((hm, 2 * (L + 1)))
+    buf[:, :n] = x
+    bd = torch.from_numpy(buf).cuda()
+    cv = bd.view(-1).view(torch.complex128)
+    pi = fa.plan_many_dft_r2c(1, [n], hm, bd, None, 1, 2 * (L + 1), cv, None, 1, L + 1)
+    assert len(pi.steps()) == 1, pi.sprint()
+    pi.execute()
+    pi.sync()
+    assert aerror(cv.cpu().numpy().reshape(hm, L + 1), want) <= TOL, L
+    qi = fa.plan_many_dft_c2r(1, [n], hm, cv, None, 1, L + 1, bd, None, 1, 2 * (L + 1))
+    assert len(qi.steps()) == 1, qi.sprint()
+    qi.execute()
+    qi.sync()
+    assert aerror(bd.cpu().numpy()[:, :n], x * n) <= TOL, L

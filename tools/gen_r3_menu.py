@@ -154,9 +154,32 @@ def extend():
     print("%d new lengths, %d in all" % (len(best), len(rows)), file=sys.stderr)
 
 
+def real_subset():
+    """--real: r3r_menu.inc, the lengths whose rows kernel is also built in its fused real forms (r2c untangle /
+    c2r tangle, pass3g_kernel MODE 1 / 2): the 5-smooth entries of r3_menu.inc -- half lengths of the real sizes
+    people use (n = 1280 ... 15360: 1920, 2000, 3000, 3600, 4000, 6000, 7200, 10000, 12000 ...)."""
+    with open(os.path.join(CSRC, "r3_menu.inc")) as f:
+        rows = [tuple(int(v) for v in m.groups()) for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read())]
+
+    def smooth5(n):
+        for p in (2, 3, 5):
+            while n % p == 0:
+                n //= p
+        return n == 1
+    rows = [r for r in rows if smooth5(r[0])]
+    with open(os.path.join(CSRC, "r3r_menu.inc"), "w") as f:
+        f.write("/* generated by tools/gen_r3_menu.py --real -- X(L, R1, R2, R3): rows kernels of r3_menu.inc that are\n"
+                "   also built with the fused r2c untangle / c2r tangle (half length L of real rows of 2L) */\n")
+        for r in rows:
+            f.write("X(%d, %d, %d, %d)\n" % r)
+    print("%d real-rows lengths" % len(rows), file=sys.stderr)
+
+
 def main():
     if "--extend" in sys.argv:
         return extend()
+    if "--real" in sys.argv:
+        return real_subset()
     have2 = rr_menu()
     cands = []
     for L in range(513, 4097):
