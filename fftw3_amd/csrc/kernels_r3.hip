@@ -203,6 +203,8 @@ extern "C" int fa_hip_r2c_rows_tile(int L) {
 /* A step with FFTW_AMD_F_R2C_ROWS / FFTW_AMD_F_C2R_ROWS has no other executor: the planner only emits it for
    layouts this kernel takes (r2c_rows_layout_ok), so anything else here is a caller error
    (new-array execution with differently aligned arrays) and fails loudly. */
+extern "C" int fa_hip_r2c_rows2m_tile(int L);      /* kernels_r2cm.hip: mixed-radix two-stage lengths, plain r2c / c2r */
+int fa_launch_r2crows2m(int L, const R2CRArgs &ra, dim3 grid, hipStream_t st, bool inverse);
 extern "C" int fa_hip_r2c_rows3_tile(int L);
 int fa_launch_r2crows3(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                        i64 cs, i64 cn, hipStream_t st);
@@ -210,19 +212,20 @@ int fa_launch_r2crows3(const fftw_amd_step_desc *d, double *const *bufs, void *c
 int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                       i64 cs, i64 cn, hipStream_t st) {
     /* half lengths above 1024: the three-stage form (kernels_rr.hip) */
-    if (fa_hip_r2c_rows_tile(d->L) <= 0 && fa_hip_r2c_rows3_tile(d->L) > 0)
+    const bool mixed2 = fa_hip_r2c_rows_tile(d->L) <= 0 && fa_hip_r2c_rows2m_tile(d->L) > 0;
+    if (fa_hip_r2c_rows_tile(d->L) <= 0 && !mixed2 && fa_hip_r2c_rows3_tile(d->L) > 0)
         return fa_launch_r2crows3(d, bufs, tables, cs, cn, st);
     R2CRArgs ra;
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
-    const int T = fa_hip_r2c_rows_tile(d->L);
+    const int T = mixed2 ? fa_hip_r2c_rows2m_tile(d->L) : fa_hip_r2c_rows_tile(d->L);
     const bool fwd = (d->flags & FFTW_AMD_F_R2C_ROWS) != 0;
     const int epi = (int)d->aux_valid;                 /* fused r2r epilogue (r2c) / prologue (c2r), or 0 */
     const int pre = (fwd && d->aux_buf > 0) ? d->aux_buf : 0;   /* in-row gather of the r2r pre-processing */
     const int post = (!fwd && d->aux_buf > 0) ? d->aux_buf : 0; /* output shuffle in the c2r rows store */
     const bool real_src = (!fwd && epi) || pre, real_dst = (fwd && epi) || post;
     if (T <= 0 || d->tile != T || (!real_src && (d->src_im != 1 || d->is_l != 2)) ||
-        (!real_dst && (d->dst_im != 1 || d->os_l != 2))) {
+        (!real_dst && (d->dst_im != 1 || d->os_l != 2)) || (mixed2 && (epi || pre || post))) {
         fprintf(stderr, "fftw3_amd: internal error: fused r2c rows step with an unsupported layout\n");
         abort();
     }
@@ -276,6 +279,11 @@ int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *co
     case 256: launch_r2cr<16, 16>(ra, grid, st, inverse); break;
     case 512: launch_r2cr<32, 16>(ra, grid, st, inverse); break;
     case 1024: launch_r2cr<32, 32>(ra, grid, st, inverse); break;
+    default:
+        if (fa_launch_r2crows2m(d->L, ra, grid, st, inverse)) {
+            fprintf(stderr, "fftw3_amd: internal error: no fused real-rows kernel for half length %d\n", d->L);
+            abort();
+        }
     }
     return 0;
 }

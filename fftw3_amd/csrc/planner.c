@@ -1225,14 +1225,18 @@ static int c2r_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc cur, fa_l
     return 1;
 }
 
-/* rows per tile of the one-trip real-rows kernels for half length `half` (0: none): the two-stage form carries the
-   r2r hooks, the three-stage form (2048 ... 8192) only the plain r2c / c2r */
+/* rows per tile of the one-trip real-rows kernels for half length `half` (0: none): the power-of-two two-stage
+   form carries the r2r hooks; its mixed-radix lengths (r2cr_menu.inc) and the three-stage form (640 ... 8192) only
+   the plain r2c / c2r */
 static int real_rows_tile(i64 half, int hooks) {
     int t;
     if (half > 8192) return 0;
     t = fa_hip_r2c_rows_tile((int)half);
     if (t > 0) return t;
-    if (hooks || getenv("FFTW_AMD_NO_3S")) return 0;
+    if (hooks) return 0;
+    t = fa_hip_r2c_rows2m_tile((int)half);
+    if (t > 0) return t;
+    if (getenv("FFTW_AMD_NO_3S")) return 0;
     return fa_hip_r2c_rows3_tile((int)half);
 }
 

@@ -1,13 +1,14 @@
 """exploration / soak: random problems of every kind against the oracle for a fixed time
 (not collected by pytest).  usage: python tests/stress_random.py SECONDS [SEED]"""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fftw3_amd as fa
 from util import TOL, aerror, crand, rrand, oracle_dft, oracle_r2c, oracle_c2r, oracle_r2r
 
 def rand_n(rng, budget):
-    primes = [2, 2, 2, 3, 3, 5, 5, 7, 11, 13]
+    primes = [2, 2, 2, 2, 3, 3, 3, 5, 5, 7, 11, 13, 17, 19, 23]
     n = 1
     while True:
         f = primes[int(rng.integers(0, len(primes)))]

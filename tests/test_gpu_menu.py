@@ -213,15 +213,27 @@ def menu3r():
 MENU3R = menu3r()
 
 
-@pytest.mark.parametrize("L,r1,r2,r3", MENU3R + [(2048, 8, 16, 16), (4096, 16, 16, 16), (8192, 32, 16, 16)],
-                         ids=[str(m[0]) for m in MENU3R] + ["2048", "4096", "8192"])
-def test_three_stage_real_rows(L, r1, r2, r3):
-    """real rows of n = 2L in one trip (pass3g / pass3s MODE 1, 2): r2c with a ragged last tile against the oracle, c2r of
-    the result (out of place: input preserved; then in FFTW's padded in-place layout) against n x"""
+def menu2r():
+    out = []
+    with open(os.path.join(ROOT, "fftw3_amd", "csrc", "r2cr_menu.inc")) as f:
+        for m in re.finditer(r"X\((\d+), (\d+), (\d+)\)", f.read()):
+            out.append(tuple(int(v) for v in m.groups()) + (1,))
+    return out
+
+
+MENU2R = menu2r()
+
+
+@pytest.mark.parametrize("L,r1,r2,r3", MENU2R + MENU3R + [(2048, 8, 16, 16), (4096, 16, 16, 16), (8192, 32, 16, 16)],
+                         ids=[str(m[0]) for m in MENU2R + MENU3R] + ["2048", "4096", "8192"])
+def test_mixed_and_three_stage_real_rows(L, r1, r2, r3):
+    """real rows of n = 2L in one trip -- the mixed-radix two-stage lengths of r2cr_menu.inc (r2crows.hpp) and the
+    three-stage lengths (pass3g / pass3s MODE 1, 2): r2c with a ragged last tile against the oracle, c2r of the result
+    (out of place: input preserved; then in FFTW's padded in-place layout) against n x"""
     import torch
     from util import oracle_r2c, oracle_c2r, rrand
     assert r1 * r2 * r3 == L
-    n, hm = 2 * L, 11
+    n, hm = 2 * L, (11 if L > 648 else 4096 // L * 2 + 3)
     rng = np.random.default_rng(L)
     x = rrand(rng, hm, n)
     xd = torch.from_numpy(x).cuda()

@@ -9,9 +9,9 @@ import fftw3_amd as fa
 gib = int(os.environ.get("GIB", "4"))
 x = torch.view_as_complex(torch.rand(((gib << 30) // 16, 2), dtype=torch.float64, device="cuda") - 0.5)
 y = torch.zeros_like(x)
-shapes = [(1 << k,) for k in range(10, 25)] + [(n,) for n in (
+shapes = [(n,) for n in (8, 16, 17, 32, 64, 100, 256, 512)] + [(1 << k,) for k in range(10, 25)] + [(n,) for n in (
     1000, 1080, 1920, 2000, 3000, 3600, 5000, 10000, 15015, 30030, 60060, 100000, 250000, 518400, 1000000, 1105920,
-    2000000, 10000000, 15375360, 143, 1001, 17, 1031, 65537, 17408)] + [
+    2000000, 10000000, 15375360, 143, 1001, 1100, 4004, 6000, 1031, 65537, 17408)] + [
     (1024, 1024), (1080, 1920), (2048, 2048), (4096, 4096), (128, 128, 128), (256, 256, 256), (100, 100, 100)]
 print("%-18s %9s %9s %8s %7s  %s" % ("shape", "howmany", "ms", "GFLOPS", "whole%", "plan"))
 for shape in shapes:
