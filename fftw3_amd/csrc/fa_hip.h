@@ -20,6 +20,8 @@ int   fa_hip_r2c_rows_tile(int L);  /* rows per tile of the fused real-rows kern
 int   fa_hip_r2c_rows2m_tile(int L); /* ... of the mixed-radix two-stage lengths (plain r2c / c2r, half length 72 ... 648), 0: none */
 int   fa_hip_r2c_rows3_tile(int L); /* ... of its three-stage form (plain r2c / c2r, half length 2048 ... 8192), 0: none */
 int   fa_hip_r3_tile(int L);   /* rows per tile of the three-stage rows kernel for length L, 0: none */
+int   fa_hip_blue_nb(int need);  /* smallest padded length >= need of the one-kernel Bluestein, 0: none */
+int   fa_hip_blue_tile(int nb);  /* its rows per tile */
 int   fa_hip_r1_tile(int L);   /* rows per tile of the one-stage rows kernel (L = 2 ... 32), 0: none */
 void *fa_hip_malloc(size_t nbytes);
 void  fa_hip_free(void *p);

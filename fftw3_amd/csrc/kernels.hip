@@ -1135,6 +1135,9 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
                      i64 cs, i64 cn, hipStream_t st);
 int fa_launch_passrr(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                      i64 cs, i64 cn, hipStream_t st);
+/* kernels_blue.hip */
+int fa_launch_blue(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                   i64 cs, i64 cn, hipStream_t st);
 /* kernels_r1.hip */
 int fa_launch_pass1r(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                      i64 cs, i64 cn, hipStream_t st);
@@ -1299,6 +1302,7 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
     PassArgs pa;
     if (d->flags & (FFTW_AMD_F_R2C_ROWS | FFTW_AMD_F_C2R_ROWS)) return fa_launch_r2crows(d, bufs, tables, cs, cn, st);
     if (d->variant == FFTW_AMD_K_P1024 && launch_p1024(d, bufs, tables, cs, cn, st) == 0) return 0;
+    if (d->variant == FFTW_AMD_K_BLUE) return fa_launch_blue(d, bufs, tables, cs, cn, st);
     if (d->variant == FFTW_AMD_K_R1 && fa_launch_pass1r(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_RR && fa_launch_passrr(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_R3 && (fa_launch_pass3s(d, bufs, tables, cs, cn, st) == 0 ||

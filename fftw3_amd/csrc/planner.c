@@ -923,6 +923,44 @@ static int long_rows_ok(const plan *p, const fa_axis *ax) {
     return 1;
 }
 
+/* Bluestein for interleaved unit-stride rows whose padded length fits one workgroup: the whole algorithm in ONE
+   kernel (pass3b.hpp).  The padded length comes from a ladder (blue_menu.inc); when its first entry >= 2n - 1 is
+   more than 1.35 x that (short lengths: the ladder starts at 539) the step-by-step plan with its tighter
+   nb = next smooth number is kept.  Like the long rows the step has no fallback, so the same plan-time conditions
+   apply (long_rows_ok).  1 = emitted. */
+static int emit_bluestein_rows(plan *p, const fa_axis *ax) {
+    i64 need = 2 * ax->n - 1;
+    int nb, j, nd = 0;
+    sdim d[FA_MAXLOOPS];
+    fftw_amd_step_desc *s;
+    if (getenv("FFTW_AMD_NO_TUNED") || getenv("FFTW_AMD_NO_3S") || getenv("FFTW_AMD_NO_BLUE_ROWS")) return 0;
+    if (ax->n < 2 || need > 8192 || ax->nloops == 0) return 0;
+    nb = fa_hip_blue_nb((int)need);
+    if (nb <= 0 || (double)nb > 1.35 * (double)need) return 0;
+    if (!long_rows_ok(p, ax)) return 0;
+    for (j = 0; j < ax->nloops; ++j) {
+        d[nd].n = ax->loops[j].n; d[nd].is = ax->loops[j].is; d[nd].os = ax->loops[j].os;
+        d[nd].tw = 0; d[nd].is_batch = (j == ax->batch_loop); ++nd;
+    }
+    emit_pass(p, ax->src, ax->dst, nb, 2, 2, d, nd, 0,
+              (ax->flags_in & FFTW_AMD_F_SWAP_IN) | (ax->flags_out & FFTW_AMD_F_SWAP_OUT));
+    if (p->failed) return 1;
+    s = &p->steps[p->nsteps - 1];
+    if (s->tile_lo_n != 1) { p->failed = 1; return 1; }
+    s->variant = FFTW_AMD_K_BLUE;
+    s->tile = fa_hip_blue_tile(nb);
+    s->aux_n = ax->n;
+    s->tw_lo = tab_chirp(p, ax->n, nb);
+    s->tw_hi = tab_blue_kernel(p, ax->n, nb);
+    /* emit_pass counted 5 nb log2 nb once; the kernel runs the stages twice plus three pointwise products */
+    {
+        double rows = 1.0;
+        for (j = 0; j < ax->nloops; ++j) rows *= (double)ax->loops[j].n;
+        p->est_flops += rows * (5.0 * (double)nb * log2((double)nb) + 18.0 * (double)nb);
+    }
+    return 1;
+}
+
 static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     fa_axis ax = *ax_in;
     i64 lens[FA_MAXPASS];
@@ -933,6 +971,7 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     if (p->failed) return;
 
     if (!fa_lds_able(ax.n)) {
+        if (emit_bluestein_rows(p, &ax)) return;
         if (fa_is_prime(ax.n) && fa_lds_able(ax.n - 1)) emit_rader(p, &ax);
         else emit_bluestein(p, &ax);
         return;
@@ -2485,6 +2524,7 @@ char *fa_sprint(const plan *p) {
             else if (d->variant == FFTW_AMD_K_RR) sapp(s, cap, &len, "reg2");
             else if (d->variant == FFTW_AMD_K_R3) sapp(s, cap, &len, "reg3");
             else if (d->variant == FFTW_AMD_K_R1) sapp(s, cap, &len, "reg1");
+            else if (d->variant == FFTW_AMD_K_BLUE) sapp(s, cap, &len, "bluestein-rows n=%lld", (long long)d->aux_n);
             else {
                 sapp(s, cap, &len, "lds:");
                 for (j = 0; j < d->nradices; ++j)

@@ -183,7 +183,9 @@ enum {
     FFTW_AMD_K_R3 = 3,          /* register-resident three-stage kernels (rows up to 4096; strided up to 1008) */
     FFTW_AMD_K_R2C = 4,         /* fused real rows -> half spectra (r2crows.hpp), with FFTW_AMD_F_R2C_ROWS */
     FFTW_AMD_K_C2R = 5,         /* fused half spectra -> real rows, with FFTW_AMD_F_C2R_ROWS */
-    FFTW_AMD_K_R1 = 6           /* one-stage register kernel: dense rows of 2 ... 32 points, one butterfly per row */
+    FFTW_AMD_K_R1 = 6,          /* one-stage register kernel: dense rows of 2 ... 32 points, one butterfly per row */
+    FFTW_AMD_K_BLUE = 7         /* Bluestein's algorithm for a whole row in one kernel (pass3b.hpp): L = padded length nb,
+                                   aux_n = n, tw_lo / tw_hi = ids of the chirp and the kernel table */
 };
 
 enum {

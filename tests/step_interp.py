@@ -127,6 +127,25 @@ class Interp(object):
                 twb = twb + gi * dtw[i]
             rad = [s.radices[i] for i in range(s.nradices)]
             assert int(np.prod(rad)) == L if rad else L == 1
+            if s.variant == 7:
+                # FFTW_AMD_K_BLUE: Bluestein for a whole row in one kernel -- L = padded length nb, aux_n = n,
+                # tw_lo / tw_hi = chirp and kernel tables (pass3b.hpp)
+                n = s.aux_n
+                assert 2 * n - 1 <= L and s.tw_n == 0
+                g2 = _grids([n] + dn)
+                so2 = sbase + g2[0] * s.is_l
+                do2 = dbase + g2[0] * s.os_l
+                for i, gi in enumerate(g2[1:]):
+                    so2 = so2 + gi * dis[i]
+                    do2 = do2 + gi * dos[i]
+                x = _load(src, so2, s.src_im, s.flags & fa.F_SWAP_IN)
+                chirp = self.table(s.tw_lo)[:n].reshape([n] + [1] * len(dn))
+                kern = self.table(s.tw_hi).reshape([L] + [1] * len(dn))
+                b = np.zeros((L,) + x.shape[1:], dtype=np.complex128)
+                b[:n] = x * np.conj(chirp)
+                c = np.fft.ifft(np.fft.fft(b, axis=0) * kern, axis=0) * L
+                _store(dst, do2, s.dst_im, s.flags & fa.F_SWAP_OUT, c[:n] * np.conj(chirp))
+                return
             if s.flags & fa.F_C2R_ROWS:
                 # fused c2r: L + 1 spectrum entries per row -> 2L reals stored as L (re, im) pairs
                 g2 = _grids([L + 1] + dn)

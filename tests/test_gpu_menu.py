@@ -267,3 +267,55 @@ def test_mixed_and_three_stage_real_rows(L, r1, r2, r3):
     qi.execute()
     qi.sync()
     assert aerror(bd.cpu().numpy()[:, :n], x * n) <= TOL, L
+
+
+def blue_menu():
+    out = []
+    with open(os.path.join(ROOT, "fftw3_amd", "csrc", "blue_menu.inc")) as f:
+        for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read()):
+            out.append(int(m.group(1)))
+    return out
+
+
+BLUE = blue_menu()
+
+
+def _largest_fitting_hard_length(nb, lo):
+    """largest n with 2n - 1 <= nb, above lo, whose largest prime factor exceeds 31 (so the planner needs Bluestein)"""
+    def lpf(v):
+        p, best = 2, 1
+        while p * p <= v:
+            while v % p == 0:
+                best, v = p, v // p
+            p += 1
+        return max(best, v) if v > 1 else best
+    n = (nb + 1) // 2
+    while n > lo and lpf(n) <= 31:
+        n -= 1
+    return n if n > lo else 0
+
+
+@pytest.mark.parametrize("idx", list(range(len(BLUE))), ids=[str(v) for v in BLUE])
+def test_bluestein_rows_kernel(idx, monkeypatch):
+    """every padded length of blue_menu.inc: rows of the largest length that needs it, forward out of place with a
+    ragged last tile and backward in place, against the oracle; the step-by-step plan (FFTW_AMD_NO_BLUE_ROWS) agrees"""
+    import torch
+    nb = BLUE[idx]
+    n = _largest_fitting_hard_length(nb, (BLUE[idx - 1] + 1) // 2 if idx else 200)
+    if not n:
+        pytest.skip("no length needs this padded size")
+    hm = 2 * max(1, 8192 // nb) + 1
+    p, e = _run(n, hm, 1, n)
+    assert "pass-%d/bluestein-rows n=%d" % (nb, n) in p.sprint() and len(p.steps()) == 1, p.sprint()
+    assert e <= TOL, (n, e)
+    rng = np.random.default_rng(n)
+    x = crand(rng, hm * n)
+    xd = torch.from_numpy(x).cuda()
+    q = fa.plan_many_dft(1, [n], hm, xd, None, 1, n, xd, None, 1, n, fa.BACKWARD)
+    assert "bluestein-rows" in q.sprint(), q.sprint()
+    q.execute()
+    q.sync()
+    assert aerror(xd.cpu().numpy(), oracle_dft(x, (n,), hm, sign=+1)) <= TOL, n
+    monkeypatch.setenv("FFTW_AMD_NO_BLUE_ROWS", "1")
+    p, e = _run(n, hm, 1, n)
+    assert "bluestein-rows" not in p.sprint() and e <= TOL, (n, e)

@@ -175,9 +175,31 @@ def real_subset():
     print("%d real-rows lengths" % len(rows), file=sys.stderr)
 
 
+def blue_ladder():
+    """--blue: blue_menu.inc, the padded lengths the one-kernel Bluestein (pass3b.hpp) is built for: a ladder through
+    r3_menu.inc in steps of about 4.5 % (a length n takes the first entry >= 2n - 1)."""
+    with open(os.path.join(CSRC, "r3_menu.inc")) as f:
+        rows = sorted(tuple(int(v) for v in m.groups()) for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read()))
+    sel, last = [], 0
+    for r in rows:
+        if r[0] >= last * 1.045:
+            sel.append(r)
+            last = r[0]
+    if rows[-1] not in sel:
+        sel.append(rows[-1])
+    with open(os.path.join(CSRC, "blue_menu.inc"), "w") as f:
+        f.write("/* generated by tools/gen_r3_menu.py --blue -- X(NB, R1, R2, R3): padded lengths of the one-kernel Bluestein\n"
+                "   (pass3b.hpp): a ladder through r3_menu.inc in steps of about 4.5 % */\n")
+        for r in sel:
+            f.write("X(%d, %d, %d, %d)\n" % r)
+    print("%d padded lengths" % len(sel), file=sys.stderr)
+
+
 def main():
     if "--extend" in sys.argv:
         return extend()
+    if "--blue" in sys.argv:
+        return blue_ladder()
     if "--real" in sys.argv:
         return real_subset()
     have2 = rr_menu()
