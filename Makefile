@@ -9,7 +9,7 @@ LIBDIR := fftw3_amd/lib
 CFLAGS := -O2 -fPIC -std=gnu99 -Wall -Wextra -Iinclude -I$(CSRC)
 HIPFLAGS := -O3 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -std=c++17 -Wall
 
-OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/sharded.o $(CSRC)/hostmath.o $(CSRC)/kernels.o $(CSRC)/kernels_rr.o $(CSRC)/kernels_r3.o $(CSRC)/kernels_r3r.o $(CSRC)/kernels_r2cm.o $(CSRC)/kernels_blue.o $(CSRC)/kernels_r1.o
+OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/sharded.o $(CSRC)/hostmath.o $(CSRC)/kernels.o $(CSRC)/kernels_rr.o $(CSRC)/kernels_rr1.o $(CSRC)/kernels_rr2.o $(CSRC)/kernels_r3.o $(CSRC)/kernels_r3r.o $(CSRC)/kernels_r2cm.o $(CSRC)/kernels_blue.o $(CSRC)/kernels_r1.o
 
 all: $(LIBDIR)/libfftw3_amd.so
 
@@ -20,7 +20,11 @@ $(CSRC)/%.o: $(CSRC)/%.c $(CSRC)/fa_plan.h $(CSRC)/fa_hip.h $(CSRC)/split_costs.
 HIPCOMMON := $(CSRC)/common.hpp $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_amd.h $(CSRC)/pass1024.hpp
 $(CSRC)/kernels.o: $(CSRC)/kernels.hip $(HIPCOMMON) $(CSRC)/r2r_epi.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/kernels_rr.o: $(CSRC)/kernels_rr.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/rr_menu.inc
+$(CSRC)/kernels_rr.o: $(CSRC)/kernels_rr.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/rr_dispatch.hpp $(CSRC)/rr_menu.inc
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/kernels_rr1.o: $(CSRC)/kernels_rr1.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/rr_dispatch.hpp $(CSRC)/rr_menu.inc
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/kernels_rr2.o: $(CSRC)/kernels_rr2.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/rr_dispatch.hpp $(CSRC)/rr_menu.inc
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/kernels_r3.o: $(CSRC)/kernels_r3.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass3g.hpp $(CSRC)/r2crows.hpp $(CSRC)/r2r_epi.hpp $(CSRC)/r3_menu.inc $(CSRC)/r3t_menu.inc
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
