@@ -20,7 +20,7 @@ $(CSRC)/%.o: $(CSRC)/%.c $(CSRC)/fa_plan.h $(CSRC)/fa_hip.h $(CSRC)/split_costs.
 HIPCOMMON := $(CSRC)/common.hpp $(CSRC)/butterflies.h $(CSRC)/fa_hip.h include/fftw3_amd.h $(CSRC)/pass1024.hpp
 $(CSRC)/kernels.o: $(CSRC)/kernels.hip $(HIPCOMMON) $(CSRC)/r2r_epi.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(CSRC)/kernels_rr.o: $(CSRC)/kernels_rr.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/rr_dispatch.hpp $(CSRC)/rr_menu.inc
+$(CSRC)/kernels_rr.o: $(CSRC)/kernels_rr.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass3w.hpp $(CSRC)/rr_dispatch.hpp $(CSRC)/rr_menu.inc
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/kernels_rr1.o: $(CSRC)/kernels_rr1.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/rr_dispatch.hpp $(CSRC)/rr_menu.inc
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -10,6 +10,7 @@
 #include "pass1024.hpp"
 #include "passrr.hpp"
 #include "pass3s.hpp"
+#include "pass3w.hpp"
 
 #include "rr_dispatch.hpp"
 
@@ -98,17 +99,17 @@ static void launch_3s(const P3SArgs &pa, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((pass3s_kernel<R1>), grid, dim3(256), lds, st, pa);
 }
 
-/* contiguous rows of 2048 / 4096 / 8192 in one pass; 1 = not applicable */
+/* contiguous rows of 2048 / 4096 / 8192 / 16384 in one pass; 1 = not applicable */
 int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                      i64 cs, i64 cn, hipStream_t st) {
     P3SArgs pa;
     int bd = d->batch_dim, T;
     i64 sbase = d->src_base, dbase = d->dst_base;
-    if ((d->L != 2048 && d->L != 4096 && d->L != 8192) || d->src_im != 1 || d->dst_im != 1 || d->tw_n ||
+    if ((d->L != 2048 && d->L != 4096 && d->L != 8192 && d->L != 16384) || d->src_im != 1 || d->dst_im != 1 || d->tw_n ||
         d->is_l != 2 || d->os_l != 2 || d->tile_lo_n > 1 ||
         (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
         return 1;
-    T = 8192 / d->L;
+    T = d->L == 16384 ? 1 : 8192 / d->L;
     for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
         pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
         pa.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
@@ -135,7 +136,17 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
     dim3 grid((unsigned)nblocks, 1, 1);
     if (d->L == 2048) launch_3s<8>(pa, grid, st);
     else if (d->L == 4096) launch_3s<16>(pa, grid, st);
-    else launch_3s<32>(pa, grid, st);
+    else if (d->L == 8192) launch_3s<32>(pa, grid, st);
+    else {
+        /* 16384: one workgroup of 512 items per row (pass3w.hpp) */
+        static std::atomic<unsigned> attr_done{0};
+        const size_t lds = P3WGeom::lds_doubles * sizeof(double);
+        if (fa_attr_needed(attr_done)) {
+            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            fa_attr_set(attr_done);
+        }
+        hipLaunchKernelGGL(pass3w_kernel, grid, dim3(512), lds, st, pa);
+    }
     return 0;
 }
 

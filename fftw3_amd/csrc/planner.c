@@ -454,7 +454,7 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
             s->variant = FFTW_AMD_K_R1;     /* dense rows of a short length: one butterfly per row (pass1r.hpp) */
             s->tile = fa_hip_r1_tile((int)L);
         } else if (fa_hip_r3_tile((int)L) > 0 && is_l == 2 && os_l == 2 && tw_n == 0 && s->tile_lo_n == 1 &&
-                   (L == 2048 || L == 4096 || L == 8192 || s->dim_n[0] * 2 >= fa_hip_r3_tile((int)L))) {
+                   (L == 2048 || L == 4096 || L == 8192 || L == 16384 || s->dim_n[0] * 2 >= fa_hip_r3_tile((int)L))) {
             s->variant = FFTW_AMD_K_R3;     /* three-stage register kernel, whole contiguous rows */
             s->tile = fa_hip_r3_tile((int)L);
         } else if (fa_hip_rr_tile((int)L) > 0 && s->dim_n[0] * s->tile_lo_n * 4 >= fa_hip_rr_tile((int)L) &&
@@ -997,8 +997,9 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
                      ax.src.im == 1 && ax.dst.im == 1 &&
                      !((ax.flags_in | ax.flags_out) & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT)) &&
                      !getenv("FFTW_AMD_NO_3S");
-        /* 8192: one row per workgroup (32 x 16 x 16), one trip instead of 128 x 64 in two */
-        if (rows3s && ax.n > FA_LMAX_SINGLE) rows3s = ax.n <= 8192 && long_rows_ok(p, &ax);
+        /* 8192: one row per workgroup (32 x 16 x 16), one trip instead of 128 x 64 in two; 16384: one row per
+           512-item workgroup (pass3w.hpp) */
+        if (rows3s && ax.n > FA_LMAX_SINGLE) rows3s = ax.n <= 16384 && long_rows_ok(p, &ax);
         if (!rows3s) lmax1 = 1024;
         else if (ax.n > lmax1) lmax1 = ax.n;
     }
@@ -1199,7 +1200,7 @@ static int axis_pass_count(i64 n) {
 /* passes of the half-length complex transform of an r2c / c2r axis: its rows are contiguous, so a length with
    a three-stage rows kernel (up to 8192) is one pass */
 static int half_axis_pass_count(i64 n) {
-    if (n <= 8192 && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_3S") && fa_hip_r3_tile((int)n) > 0) return 1;
+    if (n <= 16384 && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_3S") && fa_hip_r3_tile((int)n) > 0) return 1;
     return axis_pass_count(n);
 }
 

@@ -201,19 +201,20 @@ def test_register_kernels_wide_batches(torch_dev, n):
     assert aerror(y, oracle_dft(x, (n,), 9).reshape(9, n)) < TOL
 
 
-def test_rows_of_8192_in_one_trip(torch_dev):
-    """contiguous interleaved rows of 8192 points: one workgroup per row (32 x 16 x 16, pass3s.hpp), a step
-    without an LDS-kernel fallback -- so plans that cannot promise its layout at plan time (FFTW_UNALIGNED,
-    a lone transform) keep the two-pass split; both compute the same answer"""
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_rows_of_8192_and_16384_in_one_trip(torch_dev, n):
+    """contiguous interleaved rows of 8192 / 16384 points: one workgroup per row (32 x 16 x 16 with 256 items,
+    pass3s.hpp; 32 x 16 x 32 with 512 items, pass3w.hpp), steps without an LDS-kernel fallback -- so plans that
+    cannot promise the layout at plan time (FFTW_UNALIGNED, a lone transform) keep the two-pass split; both
+    compute the same answer"""
     torch, dev = torch_dev
-    n = 8192
-    rng = np.random.default_rng(8192)
+    rng = np.random.default_rng(n)
     for b, sign in ((77, -1), (3, 1)):
         x = crand(rng, b, n)
         dx = torch.from_numpy(x).to(dev)
         dy = torch.zeros_like(dx)
         p = fa.plan_many_dft(1, [n], b, dx, None, 1, n, dy, None, 1, n, sign)
-        assert "pass-8192/reg3" in p.sprint() and len(p.steps()) == 1, p.sprint()
+        assert "pass-%d/reg3" % n in p.sprint() and len(p.steps()) == 1, p.sprint()
         p.execute()
         p.sync()
         ref = oracle_dft(x, (n,), b, sign).reshape(b, n)
@@ -235,7 +236,7 @@ def test_rows_of_8192_in_one_trip(torch_dev):
     dx = torch.from_numpy(x).to(dev)
     dy = torch.zeros(5, n + 2, dtype=torch.complex128, device=dev)
     p = fa.plan_many_dft(1, [n], 5, dx, None, 1, n + 6, dy, None, 1, n + 2, fa.FORWARD)
-    assert "pass-8192/reg3" in p.sprint(), p.sprint()
+    assert "pass-%d/reg3" % n in p.sprint(), p.sprint()
     p.execute()
     p.sync()
     assert aerror(dy.cpu().numpy()[:, :n], oracle_dft(np.ascontiguousarray(x[:, :n]), (n,), 5).reshape(5, n)) < TOL

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import fftw3_amd as fa
-n = 8192
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 hm = (8 << 30) // 16 // n
 x = (torch.rand(hm * n, dtype=torch.float64, device="cuda") - 0.5).to(torch.complex128)
 y = torch.zeros_like(x)
@@ -19,6 +19,6 @@ for no3s in (1, 0, 1, 0):
             torch.cuda.synchronize(); t0 = time.perf_counter(); p.execute(); p.sync(); ts.append(time.perf_counter() - t0)
         t = min(ts)
         print("%s %-8s %7.3f ms %6.0f GFLOPS whole %4.1f%%  %s" % ("two-pass" if no3s else "one-trip", "in place" if dst is x else "",
-              t * 1e3, 5.0 * n * 13 * hm / t / 1e9, 100 * 32.0 * n * hm / t / 8e12,
+              t * 1e3, 5.0 * n * __import__("math").log2(n) * hm / t / 1e9, 100 * 32.0 * n * hm / t / 8e12,
               " ".join(l.strip() for l in p.sprint().splitlines()[1:])), flush=True)
         del p
