@@ -480,3 +480,40 @@ def test_streaming_access_flags_only_on_the_callers_side_and_only_for_large_batc
     s2 = p2.steps()
     assert s2[0].dst_buf == 1 and not (s2[0].flags & NT_OUT)
     assert s2[-1].dst_buf == 1 and (s2[-1].flags & NT_OUT)
+
+
+def test_one_trip_rows_plans():
+    """the steps without an LDS-kernel fallback (rows above 4096 points, fused real rows above n = 2048 and for mixed
+    lengths, the one-kernel Bluestein, the one-stage rows kernel) are planned only where their layout is settled at
+    plan time; their step lists compute the right answer under the numpy interpreter"""
+    x = np.zeros(8, dtype=complex)
+    one = lambda n, b, flags=fa.ESTIMATE: fa.plan_many_dft(1, [n], b, x, None, 1, n, x.copy(), None, 1, n, fa.FORWARD, flags)
+    for n in (5000, 6561, 8192, 16384):
+        assert len(one(n, 16).steps()) == 1 and "reg3" in one(n, 16).sprint(), n
+        assert len(one(n, 16, fa.ESTIMATE | fa.UNALIGNED).steps()) == 2, n      # any alignment: keep the fallback
+        assert len(one(n, 1).steps()) == 2, n                                  # nothing to tile over
+    assert "pass-16/reg1" in one(16, 4096).sprint() and "reg1" not in one(16, 100).sprint()
+    assert "pass-2145/bluestein-rows n=1031" in one(1031, 8).sprint()
+    assert "bluestein-rows" not in one(1031, 8, fa.ESTIMATE | fa.UNALIGNED).sprint()
+    assert "bluestein-rows" not in one(37, 64).sprint()                        # the ladder would pad 7 x
+    for n, b in ((5000, 3), (16384, 2), (1031, 5), (23, 300), (1018, 2)):
+        for sign in (-1, 1):
+            e, p = _c2c(n, b, sign)
+            assert e < TOL, (n, p.sprint())
+    e, p = _c2c(16384, 2, -1, inplace=True)
+    assert e < TOL and len(p.steps()) == 1
+    for n in (1000, 4000, 10000, 16384, 32768):
+        b = 3
+        xr = rrand(rng, b, n)
+        y = np.zeros((b, n // 2 + 1), dtype=complex)
+        p = fa.plan_many_dft_r2c(1, [n], b, xr, None, 1, n, y, None, 1, n // 2 + 1)
+        assert ("r2c-rows" in p.sprint() and len(p.steps()) == 1) or n == 32768, p.sprint()
+        run_plan_on_host(p, xr, y)
+        ref = oracle_r2c(xr, (n,), b).reshape(b, n // 2 + 1)
+        assert aerror(y, ref) < TOL, n
+        z = np.zeros((b, n))
+        q = fa.plan_many_dft_c2r(1, [n], b, ref.copy(), None, 1, n // 2 + 1, z, None, 1, n)
+        assert ("c2r-rows" in q.sprint() and len(q.steps()) == 1) or n == 32768, q.sprint()
+        yy = ref.copy()
+        run_plan_on_host(q, yy, z)
+        assert aerror(z, xr * n) < TOL, n
