@@ -142,10 +142,10 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
         static std::atomic<unsigned> attr_done{0};
         const size_t lds = P3WGeom::lds_doubles * sizeof(double);
         if (fa_attr_needed(attr_done)) {
-            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             fa_attr_set(attr_done);
         }
-        hipLaunchKernelGGL(pass3w_kernel, grid, dim3(512), lds, st, pa);
+        hipLaunchKernelGGL(pass3w_kernel<0>, grid, dim3(512), lds, st, pa);
     }
     return 0;
 }
@@ -156,6 +156,7 @@ extern "C" int fa_hip_r2c_rows3g_tile(int L);     /* kernels_r3r.hip: the mixed-
 int fa_launch_r2crows3g(int L, const P3SArgs &pa, dim3 grid, hipStream_t st, bool inverse);
 extern "C" int fa_hip_r2c_rows3_tile(int L) {
     if (L == 2048 || L == 4096 || L == 8192) return 8192 / L;
+    if (L == 16384) return 1;
     return fa_hip_r2c_rows3g_tile(L);
 }
 
@@ -228,6 +229,17 @@ int fa_launch_r2crows3(const fftw_amd_step_desc *d, double *const *bufs, void *c
     if (d->L == 2048) launch_3s_real<8>(pa, grid, st, inverse);
     else if (d->L == 4096) launch_3s_real<16>(pa, grid, st, inverse);
     else if (d->L == 8192) launch_3s_real<32>(pa, grid, st, inverse);
+    else if (d->L == 16384) {
+        static std::atomic<unsigned> attr_done{0};
+        const size_t lds = P3WGeom::lds_doubles * sizeof(double);
+        if (fa_attr_needed(attr_done)) {
+            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            fa_attr_set(attr_done);
+        }
+        if (inverse) hipLaunchKernelGGL(pass3w_kernel<2>, grid, dim3(512), lds, st, pa);
+        else hipLaunchKernelGGL(pass3w_kernel<1>, grid, dim3(512), lds, st, pa);
+    }
     else if (fa_launch_r2crows3g(d->L, pa, grid, st, inverse)) {
         fprintf(stderr, "fftw3_amd: internal error: no fused real-rows kernel for half length %d\n", d->L);
         abort();

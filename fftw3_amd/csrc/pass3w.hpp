@@ -27,6 +27,9 @@ struct P3WGeom {
     static constexpr int lds_doubles = (E1 > E2 ? E1 : E2) + 16;
 };
 
+/* MODE 0: complex rows; MODE 1: real rows of 32768 -> half spectra; MODE 2: half spectra -> real rows (the fused
+   untangle / tangle of pass3s_kernel, pass3s.hpp) */
+template <int MODE>
 __global__ void __launch_bounds__(512, 1)
 pass3w_kernel(const P3SArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
@@ -42,7 +45,22 @@ pass3w_kernel(const P3SArgs a) {
 
     /* ---- stage A: one radix-32 butterfly per item */
     cplx x[R1];
-    ld_run<R1>(x, src + 2 * tid, (i64)(2 * M), (a.flags & FFTW_AMD_F_NT_IN) != 0);
+    if (MODE == 2) {
+        const cplx wb = tw2(a.tw_lo, a.tw_hi, a.tw_shift, tid);
+#pragma unroll
+        for (int i = 0; i < R1; ++i) {
+            const int l = tid + M * i;
+            cplx yk = *reinterpret_cast<const cplx *>(src + 2 * l);
+            cplx ym = *reinterpret_cast<const cplx *>(src + 2 * (G::L - l));
+            if (l == 0) { yk.y = 0.0; ym.y = 0.0; }
+            const cplx e = c_make(yk.x + ym.x, yk.y - ym.y);
+            const cplx dd = c_make(yk.x - ym.x, yk.y + ym.y);
+            const cplx o = c_mul(dd, i ? c_mul(wb, tw2(a.tw_lo, a.tw_hi, a.tw_shift, M * i)) : wb);
+            x[i] = c_make(e.y + o.x, e.x - o.y);                     /* (Im Z', Re Z') */
+        }
+    } else {
+        ld_run<R1>(x, src + 2 * tid, (i64)(2 * M), (a.flags & FFTW_AMD_F_NT_IN) != 0);
+    }
     if (a.flags & FFTW_AMD_F_SWAP_IN) {
 #pragma unroll
         for (int i = 0; i < R1; ++i) { double s = x[i].x; x[i].x = x[i].y; x[i].y = s; }
@@ -112,11 +130,49 @@ pass3w_kernel(const P3SArgs a) {
 
     /* ---- stage C: DFT-32 over a2, store X[d1 + 32 d2 + 512 c] */
     RB<R3>::run(z);
+    if (MODE == 1) {
+        /* every item untangles its own 32 outputs; the partner of k = kb + 512 c is L - kb - 512 c (only k = 0
+           wraps onto itself) and comes through the plane, real parts first */
+        constexpr int L = G::L, KS = R1 * R2;
+        const int kb = cd1 + R1 * cd2;
+        const int pb = L - kb, p0 = kb ? L - kb : 0;
+        cplx pz[R3];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < R3; ++c) plane[kb + KS * c] = z[RB<R3>::slot(c)].x;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < R3; ++c) pz[c].x = plane[c ? pb - KS * c : p0];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < R3; ++c) plane[kb + KS * c] = z[RB<R3>::slot(c)].y;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < R3; ++c) pz[c].y = plane[c ? pb - KS * c : p0];
+        const cplx wb = tw2(a.tw_lo, a.tw_hi, a.tw_shift, kb);
+#pragma unroll
+        for (int c = 0; c < R3; ++c) {
+            const cplx zk = z[RB<R3>::slot(c)];
+            const double ar = zk.x, ai = zk.y, br = pz[c].x, bi = pz[c].y;
+            const double er = 0.5 * (ar + br), ei = 0.5 * (ai - bi);
+            const double dr = 0.5 * (ar - br), di = 0.5 * (ai + bi);
+            const cplx tw = c ? c_mul(wb, tw2(a.tw_lo, a.tw_hi, a.tw_shift, KS * c)) : wb;
+            const cplx q = c_mulc(c_make(di, -dr), tw);
+            cplx yk = c_make(er + q.x, ei + q.y);
+            if (c == 0 && kb == 0) {
+                yk.y = 0.0;
+                *reinterpret_cast<cplx *>(dst + 2 * L) = c_make(er - q.x, 0.0);
+            }
+            *reinterpret_cast<cplx *>(dst + 2 * (kb + KS * c)) = yk;
+        }
+        return;
+    }
     const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
     double *p = dst + 2 * (cd1 + R1 * cd2);
 #pragma unroll
     for (int c = 0; c < R3; ++c) {
         cplx v = z[RB<R3>::slot(c)];
+        if (MODE == 2) { *reinterpret_cast<cplx *>(p + (i64)c * (2 * R1 * R2)) = c_make(v.y, v.x); continue; }
         if (sw) { double s = v.x; v.x = v.y; v.y = s; }
         st_sel(p + (i64)c * (2 * R1 * R2), v, (a.flags & FFTW_AMD_F_NT_OUT) != 0);
     }

@@ -1270,7 +1270,7 @@ static int c2r_rows_layout_ok(const plan *p, const fa_axis *ax, fa_loc cur, fa_l
    the plain r2c / c2r */
 static int real_rows_tile(i64 half, int hooks) {
     int t;
-    if (half > 8192) return 0;
+    if (half > 16384) return 0;
     t = fa_hip_r2c_rows_tile((int)half);
     if (t > 0) return t;
     if (hooks) return 0;

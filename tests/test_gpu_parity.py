@@ -681,9 +681,9 @@ def test_stock_c_client_runs_on_the_gpu(torch_dev, tmp_path):
     assert r.returncode == 0 and "client ok" in r.stdout, r.stdout
 
 
-@pytest.mark.parametrize("n", [128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768])
 def test_fused_real_rows_kernel(torch_dev, n):
-    """r2c of contiguous rows of 128 ... 16384 reals runs as ONE fused step (pass + untangle; two register stages up
+    """r2c of contiguous rows of 128 ... 32768 reals runs as ONE fused step (pass + untangle; two register stages up
     to 2048, the three-stage rows kernel above):
     batched 1-D with a ragged last tile, and as the last dimension of 2-D / 3-D transforms"""
     from util import oracle_r2c, rrand
@@ -730,7 +730,7 @@ def test_fused_real_rows_kernel(torch_dev, n):
     assert np.array_equal(yd.cpu().numpy(), y)
 
 
-@pytest.mark.parametrize("shape", [(1024,), (20, 512), (6, 10, 256), (2000,), (12, 1000), (4096,), (3, 8192), (16384,)])
+@pytest.mark.parametrize("shape", [(1024,), (20, 512), (6, 10, 256), (2000,), (12, 1000), (4096,), (3, 8192), (16384,), (2, 32768)])
 def test_inplace_padded_real_transforms(torch_dev, shape):
     """FFTW's in-place real layout (rows padded to 2 (n/2 + 1) reals): r2c then c2r in the same
     buffer, through the fused rows kernels where they apply and the general path elsewhere"""
