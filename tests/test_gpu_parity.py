@@ -414,7 +414,7 @@ def test_chunked_batches_and_ragged_tail(torch_dev):
     rng = np.random.default_rng(4)
     fa.set_chunk_bytes(1 << 20)
     try:
-        n, b = 1 << 14, 11                     # 256 KiB per transform -> chunk 4, tail 3
+        n, b = 1 << 15, 11                     # 512 KiB per transform -> chunk 2, tail 1 (2^14 runs in one trip: no scratch)
         x = crand(rng, b, n)
         xd = torch.from_numpy(x).to(dev)
         yd = torch.zeros_like(xd)
