@@ -523,7 +523,7 @@ def main():
     # ---- the other BASELINE configs, one GPU, same measurement (reported as legs, never as `value`)
     legs = []
     if world == 1 and args.workload == "c2c" and not args.no_legs and not args.batch:
-        for name in ("r2c", "mixed", "2d"):
+        for name in os.environ.get("FFTW_AMD_BENCH_LEGS", "r2c,mixed,2d").split(","):
             lr = run_workload(name, 0, max(3, args.steps // 2), 1, torch, fa, None, 1, 0, dev,
                               want_cpu=not args.no_cpu_baseline, cpu_seconds=4.0)
             lr.pop("_y")
