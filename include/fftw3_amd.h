@@ -180,7 +180,7 @@ enum {
     FFTW_AMD_K_GENERIC = 0,     /* runtime-radix LDS kernel */
     FFTW_AMD_K_P1024 = 1,       /* register-resident radix-32x32 kernel, tile of 8 */
     FFTW_AMD_K_RR = 2,          /* register-resident two-stage kernel, L = 64..512, tile of 8192/L */
-    FFTW_AMD_K_R3 = 3,          /* register-resident three-stage kernels (rows up to 4096; strided up to 1008) */
+    FFTW_AMD_K_R3 = 3,          /* register-resident three-stage kernels (rows up to 8192 and of 16384 points; strided up to 2048) */
     FFTW_AMD_K_R2C = 4,         /* fused real rows -> half spectra (r2crows.hpp), with FFTW_AMD_F_R2C_ROWS */
     FFTW_AMD_K_C2R = 5,         /* fused half spectra -> real rows, with FFTW_AMD_F_C2R_ROWS */
     FFTW_AMD_K_R1 = 6,          /* one-stage register kernel: dense rows of 2 ... 32 points, one butterfly per row */
