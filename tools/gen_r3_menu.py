@@ -187,6 +187,7 @@ def blue_ladder():
             last = r[0]
     if rows[-1] not in sel:
         sel.append(rows[-1])
+    sel.append((8192, 32, 16, 16))          # the power of two on top: lengths up to 4096
     with open(os.path.join(CSRC, "blue_menu.inc"), "w") as f:
         f.write("/* generated by tools/gen_r3_menu.py --blue -- X(NB, R1, R2, R3): padded lengths of the one-kernel Bluestein\n"
                 "   (pass3b.hpp): a ladder through r3_menu.inc in steps of about 4.5 % */\n")
