@@ -17,6 +17,7 @@ int   fa_hip_device_count(void);
 int   fa_hip_rr_tile(int L);
 int   fa_hip_r3t_tile(int L);  /* sequences per tile of the strided three-stage kernel, 0: none */
 int   fa_hip_r2c_rows_tile(int L);  /* rows per tile of the fused real-rows kernel for half length L, 0: none */
+int   fa_hip_r2c_rows1_tile(int L);  /* ... of the one-stage real-rows kernel (dense rows, half length 2 ... 32), 0: none */
 int   fa_hip_r2c_rows2m_tile(int L); /* ... of the mixed-radix two-stage lengths (plain r2c / c2r, half length 72 ... 648), 0: none */
 int   fa_hip_r2c_rows3_tile(int L); /* ... of its three-stage form (plain r2c / c2r, half length 2048 ... 8192), 0: none */
 int   fa_hip_r3_tile(int L);   /* rows per tile of the three-stage rows kernel for length L, 0: none */

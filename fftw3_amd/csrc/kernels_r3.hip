@@ -204,6 +204,8 @@ extern "C" int fa_hip_r2c_rows_tile(int L) {
 /* A step with FFTW_AMD_F_R2C_ROWS / FFTW_AMD_F_C2R_ROWS has no other executor: the planner only emits it for
    layouts this kernel takes (r2c_rows_layout_ok), so anything else here is a caller error
    (new-array execution with differently aligned arrays) and fails loudly. */
+int fa_launch_r2crows1(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                       i64 cs, i64 cn, hipStream_t st);
 extern "C" int fa_hip_r2c_rows2m_tile(int L);      /* kernels_r2cm.hip: mixed-radix two-stage lengths, plain r2c / c2r */
 int fa_launch_r2crows2m(int L, const R2CRArgs &ra, dim3 grid, hipStream_t st, bool inverse);
 extern "C" int fa_hip_r2c_rows3_tile(int L);
@@ -213,6 +215,7 @@ int fa_launch_r2crows3(const fftw_amd_step_desc *d, double *const *bufs, void *c
 int fa_launch_r2crows(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                       i64 cs, i64 cn, hipStream_t st) {
     /* half lengths above 1024: the three-stage form (kernels_rr.hip) */
+    if (d->L <= 32) return fa_launch_r2crows1(d, bufs, tables, cs, cn, st);      /* one butterfly per row (kernels_r1.hip) */
     const bool mixed2 = fa_hip_r2c_rows_tile(d->L) <= 0 && fa_hip_r2c_rows2m_tile(d->L) > 0;
     if (fa_hip_r2c_rows_tile(d->L) <= 0 && !mixed2 && fa_hip_r2c_rows3_tile(d->L) > 0)
         return fa_launch_r2crows3(d, bufs, tables, cs, cn, st);

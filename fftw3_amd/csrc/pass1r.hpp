@@ -117,4 +117,124 @@ pass1r_kernel(const P3SArgs a) {
 
 #undef FA_P1R_LP
 
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Dense REAL rows of n = 2R = 4 ... 64 points <-> half spectra of R + 1 entries, one work-item per row: the pair   */
+/* sequence z[j] = x[2j] + i x[2j+1] is the row itself read as R complex numbers, its DFT is one butterfly, and the  */
+/* untangle / tangle (hc2cfdft / hc2cbdft, fftw/fftw_api.c:5831-5845) pairs Z[k] with Z[R-k] inside the item's own   */
+/* registers.  The real side is one contiguous run of T R complex slots, the complex side one of T (R + 1): both go  */
+/* through the LDS plane in coalesced order, as in pass1r_kernel.  FWD: r2c; else c2r (unnormalised backward).       */
+/* ------------------------------------------------------------------------------------------------------------ */
+template <int R> struct P1RRealGeom {
+    static constexpr int Q = P1RGeom<R>::Q, T = P1RGeom<R>::T;
+    static constexpr int NR = Q * R;                          /* real-side complex slots per item */
+    static constexpr int NC = Q * (R + 1);                    /* complex-side entries per item */
+    static constexpr int S = (R + 1) | 1;                     /* LDS row stride for both images, odd */
+    static constexpr int lds_doubles = T * S + 16;
+};
+
+template <int R, bool FWD>
+__global__ void __launch_bounds__(256, 2)
+pass1r_real_kernel(const P3SArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double plane[];
+    typedef P1RRealGeom<R> G;
+    constexpr int Q = G::Q, T = G::T, S = G::S;
+    constexpr int WI = FWD ? R : R + 1, WO = FWD ? R + 1 : R;        /* entries per row on the load / store side */
+    constexpr int NI = Q * WI, NO = Q * WO;
+    const int tid = threadIdx.x;
+
+    i64 tile, soff, doff, twb_unused;
+    fa_block_offsets<false>(a, tile, soff, doff, twb_unused);
+    const i64 t0 = tile * T;
+    const i64 left = a.dn[0] - t0;
+    const int rows = (int)(left < T ? left : T);
+    const double *src = a.src + soff + t0 * (2 * WI);
+    double *dst = a.dst + doff + t0 * (2 * WO);
+    const int icur = rows * WI, ocur = rows * WO;
+
+    cplx v[NI > NO ? NI : NO];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int e = j * 256 + tid;
+        v[j] = e < icur ? *reinterpret_cast<const cplx *>(src + 2 * e) : c_make(0.0, 0.0);
+    }
+#define FA_P1R_POS(j, W) (((j) * 256 + tid) + (((j) * 256 + tid) / (W)) * (S - (W)))
+    cplx x[Q][R + 1];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) plane[FA_P1R_POS(j, WI)] = v[j].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int k = 0; k < WI; ++k) x[q][k].x = plane[(q * 256 + tid) * S + k];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) plane[FA_P1R_POS(j, WI)] = v[j].y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int k = 0; k < WI; ++k) x[q][k].y = plane[(q * 256 + tid) * S + k];
+    __syncthreads();
+
+    cplx y[Q][R + 1];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (FWD) {
+            cplx z[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) z[k] = x[q][k];
+            RB<R>::run(z);
+            /* Y[k] = E + w_n^k O,  E = (Z[k] + conj Z[R-k]) / 2,  O = -i (Z[k] - conj Z[R-k]) / 2 */
+#pragma unroll
+            for (int k = 0; k <= R; ++k) {
+                const cplx zk = z[RB<R>::slot(k % R)], zm = z[RB<R>::slot((R - k) % R)];
+                const double er = 0.5 * (zk.x + zm.x), ei = 0.5 * (zk.y - zm.y);
+                const double dr = 0.5 * (zk.x - zm.x), di = 0.5 * (zk.y + zm.y);
+                const cplx p = c_mulc(c_make(di, -dr), tw2(a.tw_lo, a.tw_hi, a.tw_shift, k));
+                y[q][k] = c_make(er + p.x, ei + p.y);
+            }
+            y[q][0].y = 0.0;
+            y[q][R].y = 0.0;
+        } else {
+            /* Z'[k] = E' + i O',  E' = Y[k] + conj Y[R-k],  O' = (Y[k] - conj Y[R-k]) w_n^-k; backward DFT by the
+               (re, im) swap identity */
+            cplx z[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                cplx yk = x[q][k], ym = x[q][R - k];
+                if (k == 0) { yk.y = 0.0; ym.y = 0.0; }
+                const cplx e = c_make(yk.x + ym.x, yk.y - ym.y);
+                const cplx dd = c_make(yk.x - ym.x, yk.y + ym.y);
+                const cplx o = c_mul(dd, tw2(a.tw_lo, a.tw_hi, a.tw_shift, k));
+                z[k] = c_make(e.y + o.x, e.x - o.y);
+            }
+            RB<R>::run(z);
+#pragma unroll
+            for (int k = 0; k < R; ++k) y[q][k] = c_make(z[RB<R>::slot(k)].y, z[RB<R>::slot(k)].x);
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int k = 0; k < WO; ++k) plane[(q * 256 + tid) * S + k] = y[q][k].x;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NO; ++j) v[j].x = plane[FA_P1R_POS(j, WO)];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int k = 0; k < WO; ++k) plane[(q * 256 + tid) * S + k] = y[q][k].y;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NO; ++j) v[j].y = plane[FA_P1R_POS(j, WO)];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const int e = j * 256 + tid;
+        if (e < ocur) *reinterpret_cast<cplx *>(dst + 2 * e) = v[j];
+    }
+#undef FA_P1R_POS
+}
+
 #endif /* FA_PASS1R_HPP */

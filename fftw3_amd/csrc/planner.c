@@ -1280,6 +1280,19 @@ static int real_rows_tile(i64 half, int hooks) {
     return fa_hip_r2c_rows3_tile((int)half);
 }
 
+/* dense real rows of n = 2 half = 4 ... 64 points with at least one tile of them in a loop whose strides are exactly
+   the row lengths (n reals, half + 1 complex numbers): the one-stage real-rows kernel (pass1r.hpp); 0: not this */
+static int short_real_rows_tile(const fa_axis *ax, i64 half, int hooks, int fwd) {
+    int j, t;
+    if (hooks || half < 2 || half > 32 || getenv("FFTW_AMD_NO_R1")) return 0;
+    t = fa_hip_r2c_rows1_tile((int)half);
+    if (t <= 0) return 0;
+    for (j = 0; j < ax->nloops; ++j)
+        if (ax->loops[j].n >= 256 && ax->loops[j].is == (fwd ? 2 * half : 2 * (half + 1)) &&
+            ax->loops[j].os == (fwd ? 2 * (half + 1) : 2 * half)) return t;
+    return 0;
+}
+
 /* can the r2c / c2r axis emitters fuse an r2r epilogue / prologue for this length? */
 static int r2r_can_fuse(i64 nl) { return nl >= 2 && nl % 2 == 0 && !getenv("FFTW_AMD_R2R_UNFUSED"); }
 
@@ -1364,7 +1377,8 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
         buf_release(p, zbuf);
     } else if (nl % 2 == 0 && nl >= 2 && (pre != 0 || (ps == 2 && pim == 1)) &&
                (epi != 0 || (cs == 2 && out.im == 1)) &&
-               real_rows_tile(nl / 2, epi || pre) > 0 && r2c_rows_layout_ok(p, &ax, in, out, epi, pre)) {
+               (short_real_rows_tile(&ax, nl / 2, epi || pre, 1) > 0 || real_rows_tile(nl / 2, epi || pre) > 0) &&
+               r2c_rows_layout_ok(p, &ax, in, out, epi, pre)) {
         /* contiguous real rows of a supported length: the half-length complex DFT and the
            untangle in ONE trip (r2crows.hpp) instead of a pass plus an untangle step */
         sdim d[FA_MAXLOOPS];
@@ -1380,7 +1394,8 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
         s = &p->steps[p->nsteps - 1];
         s->variant = FFTW_AMD_K_R2C;
         s->aux_buf = pre ? pre : -1;     /* r2r pre-processing gathered inside the row (FFTW_AMD_R2R_PRE_*) */
-        s->tile = real_rows_tile(nl / 2, epi || pre);
+        s->tile = short_real_rows_tile(&ax, nl / 2, epi || pre, 1) > 0 ? short_real_rows_tile(&ax, nl / 2, epi || pre, 1)
+                                                                    : real_rows_tile(nl / 2, epi || pre);
         s->tile_lo_n = 1;
         /* aux_n = n, aux_valid = fused r2r epilogue (0: plain half spectrum), aux_base = index
            multiplier of the untangle twiddle in the table (4 with the modulus-4n table of the
@@ -1558,7 +1573,8 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         buf_release(p, zbuf);
     } else if (nl % 2 == 0 && nl >= 2 && (post != 0 || (ps == 2 && pim == 1)) &&
                (pro != 0 || (cs == 2 && cur.im == 1)) &&
-               real_rows_tile(nl / 2, pro || post) > 0 && c2r_rows_layout_ok(p, &ax, cur, out, pro, post)) {
+               (short_real_rows_tile(&ax, nl / 2, pro || post, 0) > 0 || real_rows_tile(nl / 2, pro || post) > 0) &&
+               c2r_rows_layout_ok(p, &ax, cur, out, pro, post)) {
         /* contiguous rows of a supported length: tangle + backward half-length DFT in ONE trip */
         sdim d[FA_MAXLOOPS];
         int nd = 0;
@@ -1573,7 +1589,8 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
         s = &p->steps[p->nsteps - 1];
         s->variant = FFTW_AMD_K_C2R;
         s->aux_buf = post ? post : -1;   /* r2r output shuffle done by the kernel's store (FFTW_AMD_R2R_POST_E01 / O01) */
-        s->tile = real_rows_tile(nl / 2, pro || post);
+        s->tile = short_real_rows_tile(&ax, nl / 2, pro || post, 0) > 0 ? short_real_rows_tile(&ax, nl / 2, pro || post, 0)
+                                                                        : real_rows_tile(nl / 2, pro || post);
         s->tile_lo_n = 1;
         s->aux_n = nl;              /* as in the r2c rows step: n, fused r2r prologue, twiddle multiplier */
         s->aux_valid = pro;

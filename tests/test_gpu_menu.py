@@ -319,3 +319,52 @@ def test_bluestein_rows_kernel(idx, monkeypatch):
     monkeypatch.setenv("FFTW_AMD_NO_BLUE_ROWS", "1")
     p, e = _run(n, hm, 1, n)
     assert "bluestein-rows" not in p.sprint() and e <= TOL, (n, e)
+
+
+@pytest.mark.parametrize("L", list(range(2, 33)))
+def test_one_stage_real_rows_kernel(L, monkeypatch):
+    """dense real rows of n = 2L = 4 ... 64 points in one trip, one work-item per row (pass1r_real_kernel): r2c with
+    batches that end inside a tile / inside the first run of a tile against the oracle, c2r of the result against n x
+    with its input preserved; the padded in-place layout (rows not dense) and FFTW_AMD_NO_R1 take the other kernels"""
+    import torch
+    from util import oracle_r2c, oracle_c2r, rrand
+    n = 2 * L
+    tile = 256 * (6 if L == 4 else min(8, 32 // L))
+    rng = np.random.default_rng(100 + L)
+    for hm in (2 * tile + 257, tile + 3):
+        x = rrand(rng, hm, n)
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.zeros((hm, L + 1), dtype=torch.complex128, device="cuda")
+        p = fa.plan_many_dft_r2c(1, [n], hm, xd, None, 1, n, yd, None, 1, L + 1)
+        assert "pass-%d/r2c-rows" % L in p.sprint() and len(p.steps()) == 1, p.sprint()
+        p.execute()
+        p.sync()
+        want = oracle_r2c(x, (n,), hm).reshape(hm, L + 1)
+        assert aerror(yd.cpu().numpy(), want) <= TOL, (L, hm)
+        y = yd.cpu().numpy().copy()
+        zd = torch.zeros((hm, n), dtype=torch.float64, device="cuda")
+        q = fa.plan_many_dft_c2r(1, [n], hm, yd, None, 1, L + 1, zd, None, 1, n)
+        assert "pass-%d/c2r-rows" % L in q.sprint() and len(q.steps()) == 1, q.sprint()
+        q.execute()
+        q.sync()
+        assert aerror(zd.cpu().numpy(), x * n) <= TOL, (L, hm)
+        assert np.array_equal(yd.cpu().numpy(), y)
+    hm = 700
+    x = rrand(rng, hm, n)
+    buf = np.zeros((hm, 2 * (L + 1)))
+    buf[:, :n] = x
+    bd = torch.from_numpy(buf).cuda()
+    cv = bd.view(-1).view(torch.complex128)
+    pi = fa.plan_many_dft_r2c(1, [n], hm, bd, None, 1, 2 * (L + 1), cv, None, 1, L + 1)
+    assert "r2c-rows" not in pi.sprint(), pi.sprint()
+    pi.execute()
+    pi.sync()
+    assert aerror(cv.cpu().numpy().reshape(hm, L + 1), oracle_r2c(x, (n,), hm).reshape(hm, L + 1)) <= TOL, L
+    monkeypatch.setenv("FFTW_AMD_NO_R1", "1")
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros((hm, L + 1), dtype=torch.complex128, device="cuda")
+    p = fa.plan_many_dft_r2c(1, [n], hm, xd, None, 1, n, yd, None, 1, L + 1)
+    assert "r2c-rows" not in p.sprint(), p.sprint()
+    p.execute()
+    p.sync()
+    assert aerror(yd.cpu().numpy(), oracle_r2c(x, (n,), hm).reshape(hm, L + 1)) <= TOL, L

@@ -5,8 +5,9 @@ import torch
 import fftw3_amd as fa
 tot = (2 << 30) // 8
 x = torch.rand(tot, dtype=torch.float64, device="cuda") - 0.5
-z = torch.zeros(tot // 2 + (1 << 22), dtype=torch.complex128, device="cuda")
 SIZES = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 8192, 16384, 32768, 1000, 1920, 3000, 4000, 6000, 10000]
+# the half spectra of all rows: (n / 2 + 1) / n of the real size, largest for the shortest rows
+z = torch.zeros(max((tot // n) * (n // 2 + 1) for n in SIZES) + 1024, dtype=torch.complex128, device="cuda")
 for n in SIZES:
     hm = tot // n
     for kind in ("r2c", "c2r"):
