@@ -83,18 +83,20 @@ int fa_launch_pass1r(const fftw_amd_step_desc *d, double *const *bufs, void *con
 /* ---- dense real rows of n = 2L = 4 ... 64 points <-> half spectra (pass1r_real_kernel) ------------------------ */
 
 template <int R>
-static void launch_1r_real(const P3SArgs &pa, dim3 grid, hipStream_t st, bool inverse) {
+static void launch_1r_real(const P3SArgs &pa, dim3 grid, hipStream_t st, bool inverse, bool pad) {
     static std::atomic<unsigned> attr_done{0};
     const size_t lds = P1RRealGeom<R>::lds_doubles * sizeof(double);
     if (fa_attr_needed(attr_done)) {
-        FA_CHECK(hipFuncSetAttribute((const void *)pass1r_real_kernel<R, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FA_CHECK(hipFuncSetAttribute((const void *)pass1r_real_kernel<R, false>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass1r_real_kernel<R, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass1r_real_kernel<R, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass1r_real_kernel<R, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass1r_real_kernel<R, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         fa_attr_set(attr_done);
     }
-    if (inverse) hipLaunchKernelGGL((pass1r_real_kernel<R, false>), grid, dim3(256), lds, st, pa);
-    else hipLaunchKernelGGL((pass1r_real_kernel<R, true>), grid, dim3(256), lds, st, pa);
+    if (inverse && pad) hipLaunchKernelGGL((pass1r_real_kernel<R, false, true>), grid, dim3(256), lds, st, pa);
+    else if (inverse) hipLaunchKernelGGL((pass1r_real_kernel<R, false, false>), grid, dim3(256), lds, st, pa);
+    else if (pad) hipLaunchKernelGGL((pass1r_real_kernel<R, true, true>), grid, dim3(256), lds, st, pa);
+    else hipLaunchKernelGGL((pass1r_real_kernel<R, true, false>), grid, dim3(256), lds, st, pa);
 }
 
 extern "C" int fa_hip_r2c_rows1_tile(int L) { return fa_hip_r1_tile(L); }
@@ -111,6 +113,7 @@ int fa_launch_r2crows1(const fftw_amd_step_desc *d, double *const *bufs, void *c
     const i64 rs = 2 * (i64)d->L, cst = 2 * ((i64)d->L + 1);          /* row pitch on the real / complex side */
     const i64 want_is = inverse ? cst : rs, want_os = inverse ? rs : cst;
     int dense = -1;
+    bool pad = false;
     if (T <= 0 || d->tile != T || d->src_im != 1 || d->dst_im != 1 || d->is_l != 2 || d->os_l != 2 ||
         d->aux_valid || d->aux_buf > 0 || d->tile_lo_n > 1) {
         fprintf(stderr, "fftw3_amd: internal error: short real rows step with an unsupported layout\n");
@@ -129,6 +132,12 @@ int fa_launch_r2crows1(const fftw_amd_step_desc *d, double *const *bufs, void *c
     /* the dense loop becomes the tile dim (the planner's tile dim is whichever loop has the smallest stride) */
     for (int i = 0; i < d->ndims; ++i)
         if (pa.dis[i] == want_is && pa.dos[i] == want_os && (dense < 0 || pa.dn[i] > pa.dn[dense])) dense = i;
+    if (dense < 0) {
+        /* FFTW's padded layout: both sides advance by 2 (L + 1) doubles per row */
+        for (int i = 0; i < d->ndims; ++i)
+            if (pa.dis[i] == cst && pa.dos[i] == cst && (dense < 0 || pa.dn[i] > pa.dn[dense])) dense = i;
+        pad = dense >= 0;
+    }
     pa.src = bufs[d->src_buf] + sbase;
     pa.dst = bufs[d->dst_buf] + dbase;
     bool bad = dense < 0 || ((uintptr_t)pa.src % 16) || ((uintptr_t)pa.dst % 16);
@@ -161,7 +170,7 @@ int fa_launch_r2crows1(const fftw_amd_step_desc *d, double *const *bufs, void *c
     }
     dim3 grid((unsigned)nblocks, 1, 1);
     switch (d->L) {
-#define X(R_) case R_: launch_1r_real<R_>(pa, grid, st, inverse); return 0;
+#define X(R_) case R_: launch_1r_real<R_>(pa, grid, st, inverse, pad); return 0;
         FA_R1_LENGTHS(X)
 #undef X
     }

@@ -132,13 +132,15 @@ template <int R> struct P1RRealGeom {
     static constexpr int lds_doubles = T * S + 16;
 };
 
-template <int R, bool FWD>
+/* PAD: the real rows are padded to 2 (R + 1) reals (FFTW's in-place layout): the real side is then a run of R + 1
+   slots per row too, the last one padding -- read and ignored (FWD), never written (c2r) */
+template <int R, bool FWD, bool PAD = false>
 __global__ void __launch_bounds__(256, 2)
 pass1r_real_kernel(const P3SArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
     typedef P1RRealGeom<R> G;
     constexpr int Q = G::Q, T = G::T, S = G::S;
-    constexpr int WI = FWD ? R : R + 1, WO = FWD ? R + 1 : R;        /* entries per row on the load / store side */
+    constexpr int WI = (FWD && !PAD) ? R : R + 1, WO = (FWD || PAD) ? R + 1 : R;   /* slots per row, load / store side */
     constexpr int NI = Q * WI, NO = Q * WO;
     const int tid = threadIdx.x;
 
@@ -211,6 +213,7 @@ pass1r_real_kernel(const P3SArgs a) {
             RB<R>::run(z);
 #pragma unroll
             for (int k = 0; k < R; ++k) y[q][k] = c_make(z[RB<R>::slot(k)].y, z[RB<R>::slot(k)].x);
+            if (PAD) y[q][R] = c_make(0.0, 0.0);
         }
     }
 
@@ -232,7 +235,7 @@ pass1r_real_kernel(const P3SArgs a) {
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
         const int e = j * 256 + tid;
-        if (e < ocur) *reinterpret_cast<cplx *>(dst + 2 * e) = v[j];
+        if (e < ocur && (FWD || !PAD || (e % (R + 1)) != R)) *reinterpret_cast<cplx *>(dst + 2 * e) = v[j];
     }
 #undef FA_P1R_POS
 }

@@ -1290,6 +1290,9 @@ static int short_real_rows_tile(const fa_axis *ax, i64 half, int hooks, int fwd)
     for (j = 0; j < ax->nloops; ++j)
         if (ax->loops[j].n >= 256 && ax->loops[j].is == (fwd ? 2 * half : 2 * (half + 1)) &&
             ax->loops[j].os == (fwd ? 2 * (half + 1) : 2 * half)) return t;
+    /* FFTW's padded rows (the in-place layout): 2 (half + 1) doubles per row on both sides */
+    for (j = 0; j < ax->nloops; ++j)
+        if (ax->loops[j].n >= 256 && ax->loops[j].is == 2 * (half + 1) && ax->loops[j].os == 2 * (half + 1)) return t;
     return 0;
 }
 

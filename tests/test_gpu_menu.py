@@ -356,10 +356,25 @@ def test_one_stage_real_rows_kernel(L, monkeypatch):
     bd = torch.from_numpy(buf).cuda()
     cv = bd.view(-1).view(torch.complex128)
     pi = fa.plan_many_dft_r2c(1, [n], hm, bd, None, 1, 2 * (L + 1), cv, None, 1, L + 1)
-    assert "r2c-rows" not in pi.sprint(), pi.sprint()
+    assert "pass-%d/r2c-rows" % L in pi.sprint() and len(pi.steps()) == 1, pi.sprint()   # padded rows: the PAD form
     pi.execute()
     pi.sync()
-    assert aerror(cv.cpu().numpy().reshape(hm, L + 1), oracle_r2c(x, (n,), hm).reshape(hm, L + 1)) <= TOL, L
+    want = oracle_r2c(x, (n,), hm).reshape(hm, L + 1)
+    assert aerror(cv.cpu().numpy().reshape(hm, L + 1), want) <= TOL, L
+    qi = fa.plan_many_dft_c2r(1, [n], hm, cv, None, 1, L + 1, bd, None, 1, 2 * (L + 1))
+    assert "pass-%d/c2r-rows" % L in qi.sprint() and len(qi.steps()) == 1, qi.sprint()
+    qi.execute()
+    qi.sync()
+    assert aerror(bd.cpu().numpy()[:, :n], x * n) <= TOL, L
+    # out of place into padded real rows: the padding is not written
+    yd = torch.from_numpy(want.copy()).cuda()
+    od = torch.full((hm, 2 * (L + 1)), 7.5, dtype=torch.float64, device="cuda")
+    qo = fa.plan_many_dft_c2r(1, [n], hm, yd, None, 1, L + 1, od, None, 1, 2 * (L + 1))
+    assert "pass-%d/c2r-rows" % L in qo.sprint(), qo.sprint()
+    qo.execute()
+    qo.sync()
+    o = od.cpu().numpy()
+    assert aerror(o[:, :n], x * n) <= TOL and np.all(o[:, n:] == 7.5), L
     monkeypatch.setenv("FFTW_AMD_NO_R1", "1")
     xd = torch.from_numpy(x).cuda()
     yd = torch.zeros((hm, L + 1), dtype=torch.complex128, device="cuda")
