@@ -37,11 +37,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 def workload(name, batch_override):
     """(rank dims, howmany, kind, flops per transform, algorithmic bytes per transform)"""
-    if name == "c2c":
+    if name in ("c2c", "c2c-bwd-inplace"):
         n = [1 << 20]
         b = 4096
         kind = "c2c"
-    elif name == "r2c":
+    elif name in ("r2c", "c2r"):
         n = [1 << 22]
         b = 1024
         kind = "r2c"
@@ -77,27 +77,29 @@ def workload(name, batch_override):
     else:
         flops = 2.5 * size * math.log2(size)
         abytes = 8.0 * size + 16.0 * (size // n[-1]) * (n[-1] // 2 + 1)
+        if name == "c2r":
+            kind = "c2r"
     return n, b, kind, flops, abytes
 
 
-def pmc_traffic(step, units):
-    """(HBM bytes per launch of the dominant kernel, source) from the committed PMC passes
-    (profiles/r0x_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
-    FETCH_SIZE doubled as the MI355X guide prescribes).  Counters cannot be read inside
-    this process: the per-transform figure measured on the same kernel is scaled to the
-    transforms one launch processes, and `traffic_source` says so.  (None, None) when the
-    kernel has no committed measurement."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if step.L != 1024 or step.variant != 1 or not os.path.exists(path):
-            continue
-        with open(path) as f:
-            prof = json.load(f)
-        key = "pass1024_kernel<false, true, 2" if step.tw_n else "pass1024_kernel<true, true, 0"
-        for kname, v in prof["kernels"].items():
-            if key in kname:
-                return v["traffic_bytes_per_transform"] * units, "profiles/%s (static: rocprofv3 --pmc passes of the same kernel, scaled per launch)" % name
-    return None, None
+def pmc_traffic(name, alg_bytes_per_step):
+    """(HBM-side bytes per step of the whole plan, source) from the committed PMC passes of THIS round's
+    build (profiles/r03_traffic.json: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of
+    this same bench command, FETCH_SIZE doubled as the MI355X guide prescribes for 16-B-per-lane streaming
+    reads; the counters sit on the L2's fabric side, so Infinity-Cache hits are included).  Counters cannot
+    be read inside this process, so the figure is static and `traffic_source` says so.  (None, None) when
+    the workload has no committed measurement."""
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        prof = json.load(f)
+    w = prof.get("workloads", {}).get(name)
+    if not w:
+        return None, None
+    return w["traffic_over_algorithmic"] * alg_bytes_per_step, (
+        "profiles/r03_traffic.json (static: rocprofv3 --pmc passes of the same command; %.3f x the algorithmic bytes)"
+        % w["traffic_over_algorithmic"])
 
 
 # reference numbers measured by the survey on this container's CPU (BASELINE.md section 2): the
@@ -155,8 +157,9 @@ def cpu_baseline(n, kind, flops_per_transform, target_seconds=8.0, all_cores=Tru
     size = 1
     for v in n:
         size *= v
-    # every worker holds its input, output and the oracle's tables: keep the whole leg under ~8 GiB
-    cap = max(1, min(16, int((8 << 30) // (size * 16 * 6 + 1))))
+    # every worker holds its input, output and the oracle's tables (about 6 arrays of the size): the GPU
+    # box gives one command ~270 GiB of host memory, so 16 workers fit every BASELINE config
+    cap = max(1, min(16, int((96 << 30) // (size * 16 * 6 + 1))))
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
         f.write(_CPU_WORKER)
         script = f.name
@@ -222,6 +225,8 @@ def run_workload(name, batch_override, steps, warmup, torch, fa, dist, world, ra
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
+    check = None
+    variant = "forward, out-of-place"
     if kind == "c2c":
         x = torch.empty((b, size), dtype=torch.complex128, device=dev)
         xr = torch.view_as_real(x)
@@ -229,14 +234,41 @@ def run_workload(name, batch_override, steps, warmup, torch, fa, dist, world, ra
         for r0 in range(0, b, step_rows):        # uniform [-0.5, 0.5), filled in slabs
             sl = xr[r0:r0 + step_rows]
             sl.copy_(torch.rand(sl.shape, dtype=torch.float64, device=dev, generator=gen) - 0.5)
-        y = torch.empty_like(x)
-        plan = fa.plan_many_dft(len(n), n, b, x, None, 1, size, y, None, 1, size, fa.FORWARD,
-                                fa.ESTIMATE)
+        if name == "c2c-bwd-inplace":
+            # "also backward + in-place variants" of configs[1]
+            variant = "backward, in-place"
+            y = x
+            plan = fa.plan_many_dft(len(n), n, b, x, None, 1, size, x, None, 1, size, fa.BACKWARD, fa.ESTIMATE)
+        else:
+            y = torch.empty_like(x)
+            plan = fa.plan_many_dft(len(n), n, b, x, None, 1, size, y, None, 1, size, fa.FORWARD, fa.ESTIMATE)
     elif kind == "r2r":
         x = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
         y = torch.empty_like(x)
         plan = fa.plan_many_r2r(len(n), n, b, x, None, 1, size, y, None, 1, size,
                                 [fa.REDFT10] * len(n), fa.ESTIMATE)
+    elif kind == "c2r":
+        # "then c2r of the result (round-trip error check /N)": the spectrum comes from
+        # this library's own r2c (untimed here; its parity is the r2c leg's and the GPU tests' business)
+        variant = "backward (c2r of the r2c result), out-of-place"
+        hs = size // n[-1] * (n[-1] // 2 + 1)
+        x0 = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
+        x = torch.empty((b, hs), dtype=torch.complex128, device=dev)
+        fwd = fa.plan_many_dft_r2c(len(n), n, b, x0, None, 1, size, x, None, 1, hs, fa.ESTIMATE)
+        fwd.execute()
+        torch.cuda.synchronize()
+        del fwd
+        keep = min(b, 8)
+        ref = x0[:keep].clone()
+        del x0
+        torch.cuda.empty_cache()
+        y = torch.empty((b, size), dtype=torch.float64, device=dev)
+        plan = fa.plan_many_dft_c2r(len(n), n, b, x, None, 1, hs, y, None, 1, size, fa.ESTIMATE)
+
+        def check():
+            # c2r may overwrite its input (FFTW's contract without FFTW_PRESERVE_INPUT): checked on the FIRST run only
+            got = y[:keep] / float(size)
+            return float((got - ref).abs().max() / ref.abs().max())
     else:
         hs = size // n[-1] * (n[-1] // 2 + 1)
         x = torch.rand((b, size), dtype=torch.float64, device=dev, generator=gen) - 0.5
@@ -249,6 +281,11 @@ def run_workload(name, batch_override, steps, warmup, torch, fa, dist, world, ra
             dist.barrier()
         torch.cuda.synchronize()
 
+    roundtrip = None
+    if check is not None:
+        plan.execute()
+        torch.cuda.synchronize()
+        roundtrip = check()
     for _ in range(warmup):
         plan.execute()
     barrier()
@@ -270,7 +307,10 @@ def run_workload(name, batch_override, steps, warmup, torch, fa, dist, world, ra
     gflops = flops1 * total_transforms / dt / 1e9
     alg_gbs = abytes1 * total_transforms / dt / 1e9
 
-    # ---- roofline of the dominant kernel: HIP events around every launch
+    # ---- roofline: achieved = ALGORITHMIC bytes / time -- every transform counted once,
+    # read once + written once, whatever the number of trips the plan makes -- over the timed region of
+    # this rank; the dominant kernel's own launches (HIP events around every launch, on the stream the
+    # kernel is launched on) are reported beside it under per_launch
     prof = plan.execute_profiled()
     torch.cuda.synchronize()
     roof = None
@@ -284,30 +324,34 @@ def run_workload(name, batch_override, steps, warmup, torch, fa, dist, world, ra
         # the half-length complex passes included)
         bytes_per_launch = abytes1 * units
         kernel = "step%d kind=%d L=%d variant=%d" % (prof.index(dom), st.kind, st.L, st.variant)
-        traffic, source = pmc_traffic(st, units)
+        traffic, source = pmc_traffic(name, abytes1 * b)
         if plan.paired:
-            # one launch = pass 2 of chunk c-1 + pass 1 of chunk c: both passes' bytes, except that
-            # the first and the last of the nch + 1 launches hold one pass only
+            # one launch = pass 2 of an earlier chunk + pass 1 of chunk c: both passes' bytes, except that
+            # the first and the last launches hold one pass only
             nch = (plan.batch + plan.chunk - 1) // plan.chunk
-            bytes_per_launch = 2.0 * abytes1 * units * nch / (nch + 1)
-            kernel = "pass1024_pair_kernel (pass 2 of chunk c-1 + pass 1 of chunk c in one launch)"
-            t2, _ = pmc_traffic(prof[1][0], units)
-            traffic = None if traffic is None or t2 is None else (traffic + t2) * nch / (nch + 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            nl = max(1, launches)
+            bytes_per_launch = 2.0 * abytes1 * units * nch / nl
+            kernel = "pass1024_pair_kernel (pass 2 of an earlier chunk + pass 1 of chunk c in one launch)"
+        pl_achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        whole = alg_gbs / world
         roof = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
-            "kernel": kernel,
-            "avg_launch_ms": avg_ms, "launches_per_step": launches,
-            "alg_bytes_per_launch": bytes_per_launch,
-            "whole_transform_GBs": alg_gbs / world, "whole_transform_frac": alg_gbs / world / HBM_PEAK_GBS,
+            "bound": "hbm", "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": whole / HBM_PEAK_GBS,
+            "definition": "algorithmic bytes (%d per transform: input read once + output written once) x transforms / timed region" % int(abytes1),
+            "traffic": traffic, "traffic_source": source,
+            "per_launch": {
+                "kernel": kernel, "achieved": pl_achieved, "frac": pl_achieved / HBM_PEAK_GBS,
+                "avg_launch_ms": avg_ms, "launches_per_step": launches, "alg_bytes_per_launch": bytes_per_launch,
+                "note": "bytes the launch itself reads + writes (one pass over its chunk) / its HIP-event duration, launches serialised",
+            },
             "steps_ms": [round(t[1], 4) for t in prof],
         }
     res = {
         "workload": name, "kind": kind, "n": n, "howmany": b, "size": size, "flops1": flops1, "abytes1": abytes1,
         "gflops": gflops, "alg_gbs": alg_gbs, "ms_per_step": dt / steps * 1e3,
         "ms_min": step_ms[0], "ms_median": step_ms[len(step_ms) // 2],
-        "plan": plan.sprint().replace("\n", " "), "roofline": roof, "free": free,
+        "plan": plan.sprint().replace("\n", " "), "roofline": roof, "free": free, "variant": variant,
+        "roundtrip_rel_err": roundtrip,
     }
     res["_y"] = y
     if want_cpu:
@@ -445,7 +489,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU howmany override")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather of outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="headline workload only (no r2c / mixed / 2d legs)")
+    ap.add_argument("--no-legs", action="store_true", help="headline workload only (no backward / r2c / c2r / mixed / 2d legs)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -523,23 +567,37 @@ def main():
     # ---- the other BASELINE configs, one GPU, same measurement (reported as legs, never as `value`)
     legs = []
     if world == 1 and args.workload == "c2c" and not args.no_legs and not args.batch:
-        for name in os.environ.get("FFTW_AMD_BENCH_LEGS", "r2c,mixed,2d").split(","):
+        base_cfg = {"c2c-bwd-inplace": "configs[1], backward + in-place variant (SURVEY.md 8d row 2)",
+                    "r2c": "configs[2]", "c2r": "configs[2], c2r of the r2c result (SURVEY.md 8d row 3)",
+                    "mixed": "configs[3] (sub-batch 256 of 2048: 504 GB per array do not fit one GPU)",
+                    "2d": "configs[4] (one GPU's share of 512 images on 8 GPUs)"}
+        cpu_of = {}
+        for name in os.environ.get("FFTW_AMD_BENCH_LEGS", "c2c-bwd-inplace,r2c,c2r,mixed,2d").split(","):
+            # the backward / c2r variants run the same CPU code path as their forward twins: one CPU baseline each pair
+            twin = {"c2c-bwd-inplace": "c2c", "c2r": "r2c"}.get(name)
             lr = run_workload(name, 0, max(3, args.steps // 2), 1, torch, fa, None, 1, 0, dev,
-                              want_cpu=not args.no_cpu_baseline, cpu_seconds=4.0)
+                              want_cpu=not args.no_cpu_baseline and twin is None, cpu_seconds=4.0)
             lr.pop("_y")
             torch.cuda.empty_cache()
-            legs.append({
-                "workload": "%s n=%s howmany=%d, forward, out-of-place, FFTW_ESTIMATE" % (
-                    lr["kind"], "x".join(str(v) for v in lr["n"]), lr["howmany"]),
-                "baseline_config": {"r2c": "configs[2]", "mixed": "configs[3] (sub-batch 256 of 2048: 504 GB per array do not fit one GPU)",
-                                    "2d": "configs[4] (one GPU's share of 512 images on 8 GPUs)"}[name],
+            if twin is None:
+                cpu_of[name] = lr.get("cpu_baseline")
+            leg = {
+                "workload": "%s n=%s howmany=%d, %s, FFTW_ESTIMATE" % (
+                    lr["kind"], "x".join(str(v) for v in lr["n"]), lr["howmany"], lr["variant"]),
+                "baseline_config": base_cfg[name],
                 "value": lr["gflops"], "unit": "GFLOPS", "ms_per_step": lr["ms_per_step"],
                 "ms_min": lr["ms_min"], "ms_median": lr["ms_median"], "algorithmic_GBs": lr["alg_gbs"],
                 "plan": lr["plan"],
-                "roofline": None if lr["roofline"] is None else {k: lr["roofline"][k] for k in (
-                    "bound", "achieved", "peak", "unit", "frac", "whole_transform_frac", "kernel", "avg_launch_ms", "steps_ms")},
-                "cpu_baseline": lr.get("cpu_baseline"),
-            })
+                "roofline": lr["roofline"],
+                "cpu_baseline": lr.get("cpu_baseline") if twin is None else (
+                    res.get("cpu_baseline") if twin == "c2c" else cpu_of.get(twin)),
+            }
+            if lr["roundtrip_rel_err"] is not None:
+                leg["roundtrip_rel_err"] = lr["roundtrip_rel_err"]
+                leg["roundtrip_check"] = "max |c2r(r2c(x)) / N - x| / max |x| over the first 8 transforms, bar 1e-10"
+                if not (lr["roundtrip_rel_err"] <= 1e-10):
+                    raise SystemExit("bench.py: c2r round trip off by %g" % lr["roundtrip_rel_err"])
+            legs.append(leg)
 
     if rank == 0:
         out = {
@@ -550,8 +608,8 @@ def main():
             "ms_per_step_min": res["ms_min"], "ms_per_step_median": res["ms_median"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s n=%s howmany=%d per GPU, forward, out-of-place, FFTW_ESTIMATE" % (
-                kind, "x".join(str(v) for v in n), b),
+            "config": {"workload": "%s n=%s howmany=%d per GPU, %s, FFTW_ESTIMATE" % (
+                kind, "x".join(str(v) for v in n), b, res["variant"]),
                 "algorithmic_GBs": res["alg_gbs"], "parallelism": "batch-sharded x%d" % world,
                 "plan": res["plan"]},
             "roofline": res["roofline"],

@@ -145,6 +145,9 @@ _sig("fftw_amd_plan_many_dft_c2r_sharded", _vp, C.c_int, _ip, C.c_int, C.c_int, 
 _sig("fftw_amd_execute_sharded", None, _vp)
 _sig("fftw_amd_sharded_sync", None, _vp)
 _sig("fftw_amd_sharded_all_gather", C.c_int, _vp, _vpp, C.c_int)
+_sig("fftw_amd_sharded_gather_ops", C.c_int, _vp, _vpp, C.POINTER(C.c_longlong), C.c_int)
+_sig("fftw_amd_rccl_probe", C.c_int)
+_sig("fftw_amd_plan_workspace_device", C.c_int, _vp)
 _sig("fftw_amd_sharded_num_shards", C.c_int, _vp)
 _sig("fftw_amd_sharded_device", C.c_int, _vp, C.c_int)
 _sig("fftw_amd_sharded_range", None, _vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
@@ -528,6 +531,23 @@ class ShardedPlan(object):
         if rc < 0:
             raise RuntimeError("all-gather of the output shards failed")
         return rc
+
+    def gather_ops(self, full):
+        """the RCCL calls all_gather(full) would issue: list of (kind, rank, root, send, recv, bytes);
+        kind 0 = ncclAllGather, 1 = ncclBroadcast.  Pointers may be plain integers (no call is made)."""
+        n = self.num_shards
+        cap = n * n + n
+        ops = (C.c_longlong * (6 * cap))()
+        arr = (C.c_void_p * n)(*[a if isinstance(a, int) else ptr(a) for a in full])
+        k = lib.fftw_amd_sharded_gather_ops(self.handle, arr, ops, cap)
+        if k < 0:
+            raise ValueError("bad arguments")
+        return [tuple(ops[6 * i + j] for j in range(6)) for i in range(k)]
+
+    def replica_device(self, g):
+        """device that holds replica g's tables and scratch (-1: none / empty shard)"""
+        h = lib.fftw_amd_sharded_replica(self.handle, g)
+        return lib.fftw_amd_plan_workspace_device(h) if h else -1
 
     @property
     def num_shards(self):

@@ -111,6 +111,23 @@ static plan *clone_problem(const plan *p, fa_cfg c) {
     return q;
 }
 
+/* The twin of a plan that serves arrays of ANY alignment (built with FFTW_UNALIGNED, so the planner keeps to
+   kernels that have an executor for every layout): what fa_run switches to when a new-array execution passes
+   arrays aligned differently from the ones the plan was created on.  FFTW's contract makes that the caller's
+   error (fftw3.h, new-array execute functions; A.c:433-440 does not check); the one-trip rows kernels used to
+   abort() the process on it.  NULL if the twin cannot be built. */
+plan *fa_unaligned_twin(const plan *p) {
+    plan *q = clone_problem(p, p->cfg);
+    if (!q) return NULL;
+    q->flags = (p->flags | FFTW_UNALIGNED | FFTW_ESTIMATE) & ~(unsigned)(FFTW_MEASURE | FFTW_PATIENT | FFTW_EXHAUSTIVE);
+    q->ri = p->ri; q->ii = p->ii; q->ro = p->ro; q->io = p->io;
+    q->inplace = p->inplace;
+    if (fa_build(q)) { fa_plan_free(q); return NULL; }
+    q->in_lo = p->in_lo; q->in_hi = p->in_hi; q->out_lo = p->out_lo; q->out_hi = p->out_hi;
+    q->out_written = p->out_written;
+    return q;
+}
+
 /* ------------------------------------------------------------ helpers */
 
 /* offset range touched by a strided tensor, relative to its base */
@@ -164,7 +181,7 @@ static plan *finish_locked(plan *p, double *ri, double *ii, double *ro, double *
             return NULL;
         } else if (!(p->flags & FFTW_ESTIMATE) && ri && ro && fa_hip_device_count() > 0) {
             /* FFTW_MEASURE / PATIENT / EXHAUSTIVE: time candidate configurations on the device */
-            static const size_t chunks[] = { (size_t)128 << 20, (size_t)256 << 20, (size_t)512 << 20, (size_t)1 << 30, (size_t)4 << 30 };
+            static const size_t chunks[] = { (size_t)64 << 20, (size_t)128 << 20, (size_t)256 << 20, (size_t)1 << 30, (size_t)4 << 30 };
             fa_cfg best = p->cfg, c;
             double best_ms = -1.0;
             int ci, pi, li, st, lf, nl = (p->flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1;
@@ -178,6 +195,7 @@ static plan *finish_locked(plan *p, double *ri, double *ii, double *ro, double *
                             c = p->cfg;
                             c.chunk_bytes = chunks[ci];
                             c.pipeline = pi;
+                            c.lanes = pi ? 1 : (ci < 3 ? 2 : 1);   /* small chunks: two chunk lanes; large ones: serial or the stage pipeline */
                             c.lmax_multi = li ? 512 : 1024;
                             c.small_tiles = st;
                             c.long_first = lf;
@@ -678,7 +696,7 @@ void fftw_cleanup_threads(void) {}
 void fftw_make_planner_thread_safe(void) {}
 
 /* ---- wisdom: text records "(key) chunk pipeline lmax bits ms", one per problem
-   (bits: 1 = small_tiles, 2 = long_first) */
+   (bits: 1 = small_tiles, 2 = long_first, 4 | 8 = chunk lanes - 1) */
 void fftw_forget_wisdom(void) {
     pthread_mutex_lock(&g_planner_lock);
     while (g_wisdom) { wis_entry *n = g_wisdom->next; free(g_wisdom); g_wisdom = n; }
@@ -697,7 +715,7 @@ char *fftw_export_wisdom_to_string(void) {
     len += (size_t)snprintf(s + len, cap - len, "(fftw3_amd_wisdom-1\n");
     for (w = g_wisdom; w; w = w->next)
         len += (size_t)snprintf(s + len, cap - len, "  (%s) %zu %d %d %d %.6f\n", w->key, w->cfg.chunk_bytes,
-                                w->cfg.pipeline, w->cfg.lmax_multi, (w->cfg.small_tiles ? 1 : 0) | (w->cfg.long_first ? 2 : 0), w->ms);
+                                w->cfg.pipeline, w->cfg.lmax_multi, (w->cfg.small_tiles ? 1 : 0) | (w->cfg.long_first ? 2 : 0) | (((w->cfg.lanes > 1 ? w->cfg.lanes - 1 : 0) & 3) << 2), w->ms);
     snprintf(s + len, cap - len, ")\n");
     pthread_mutex_unlock(&g_planner_lock);
     return s;
@@ -745,7 +763,7 @@ int fftw_import_wisdom_from_string(const char *input) {
         w = (wis_entry *)calloc(1, sizeof(*w));
         if (!w) { ok = 0; break; }
         snprintf(w->key, sizeof(w->key), "%s", key);
-        w->cfg.chunk_bytes = chunk; w->cfg.pipeline = pipe != 0; w->cfg.lmax_multi = lmax; w->cfg.small_tiles = (small & 1) != 0; w->cfg.long_first = (small & 2) != 0;
+        w->cfg.chunk_bytes = chunk; w->cfg.pipeline = pipe != 0; w->cfg.lmax_multi = lmax; w->cfg.small_tiles = (small & 1) != 0; w->cfg.long_first = (small & 2) != 0; w->cfg.lanes = 1 + ((small >> 2) & 3);
         w->ms = ms;
         w->next = staged;
         staged = w;
@@ -845,7 +863,8 @@ void *fftw_amd_malloc_device(size_t nbytes) {
 }
 void fftw_amd_free_device(void *p) { fa_hip_free(p); }
 /* device of the calling host thread (hipSetDevice / hipGetDevice): what fftw_amd_malloc_device allocates on and
-   what a plan created afterwards puts its tables and scratch on at its first execution */
+   what a plan created afterwards puts its tables and scratch on -- at plan creation (finish_locked ->
+   fa_device_init), so a plan belongs to the device that was current when its planner function ran */
 int fftw_amd_set_device(int device) {
     if (device < 0 || device >= fa_hip_device_count()) return -1;
     fa_hip_set_device(device);
@@ -873,6 +892,23 @@ size_t fftw_amd_plan_workspace_bytes(const fftw_plan p) {
         b += (size_t)p->tabs[i].len * (p->tabs[i].kind == FA_TAB_PERM ? sizeof(i64) : 16);
     for (i = 2; i < p->nbufs; ++i) b += (size_t)p->buf_reals[i] * sizeof(double);
     return b;
+}
+
+/* device that holds the plan's tables and scratch: -1 before the device is set up or when the plan owns none;
+   -2 if its allocations are NOT all on one device (a bug) */
+int fftw_amd_plan_workspace_device(const fftw_plan p) {
+    int i, dev = -1;
+    if (!p || fa_hip_device_count() <= 0) return -1;
+    for (i = 0; i < p->ntabs + p->nbufs; ++i) {
+        const void *q = i < p->ntabs ? p->tabs[i].dev : (i - p->ntabs >= 2 ? (const void *)p->dbuf[i - p->ntabs] : NULL);
+        int d;
+        if (!q) continue;
+        d = fa_hip_ptr_device(q);
+        if (d < 0) continue;
+        if (dev >= 0 && d != dev) return -2;
+        dev = d;
+    }
+    return dev;
 }
 
 int fftw_amd_plan_num_steps(const fftw_plan p) { return p ? p->nsteps : 0; }

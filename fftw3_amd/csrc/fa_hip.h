@@ -30,6 +30,7 @@ void *fa_hip_host_malloc(size_t nbytes);  /* pinned; NULL when no device runtime
 int   fa_hip_host_free(void *p);          /* 0 when p was not a pinned allocation */
 /* 1: device-accessible pointer (hipMalloc / managed / registered), 0: plain host */
 int   fa_hip_is_device_ptr(const void *p);
+int   fa_hip_ptr_device(const void *p);   /* owning device of a device allocation, -1 otherwise */
 void  fa_hip_memcpy_h2d(void *dst, const void *src, size_t nbytes, void *stream);
 void  fa_hip_memcpy_d2h(void *dst, const void *src, size_t nbytes, void *stream);
 void  fa_hip_memset(void *dst, int v, size_t nbytes, void *stream);

@@ -16,6 +16,7 @@ typedef long long i64;
 #define FA_MAXBUF 16
 #define FA_MAXTAB 256
 #define FA_MAXPASS 4
+#define FA_MAXLANES 4
 
 /* primes up to this get an in-LDS O(p^2) stage; larger ones go to Rader or
    Bluestein (the reference switches from its O(n^2) "generic" solver to
@@ -62,6 +63,8 @@ typedef struct {
     int lmax_multi;       /* longest sub-transform of a multi-pass split */
     int small_tiles;      /* half-size tiles in the generic LDS kernel */
     int long_first;       /* multi-pass splits run the longest sub-transform first */
+    int lanes;            /* chunk lanes: chunk c runs all its steps on stream c % lanes, scratch slot c % lanes */
+    i64 tile_elems;       /* FFTW_AMD_TILE_ELEMS: tile size of the generic LDS kernel, 0 = default (not tuned) */
 } fa_cfg;
 
 typedef struct {
@@ -121,8 +124,9 @@ struct fftw_plan_s {
        in scratch slot c % nslots */
     int nslots, split;
     int pair;                   /* both passes of the 1024 x 1024 plan in one launch per chunk (fa_hip_launch_pair1024) */
-    void *pstream[2];
-    void *ev_a[4], *ev_b[4], *ev_begin, *ev_end[2];
+    int lanes;                  /* > 1: chunk lanes (see fa_cfg.lanes); the streams are pstream[0 .. lanes) */
+    void *pstream[FA_MAXLANES];
+    void *ev_a[4], *ev_b[4], *ev_begin, *ev_end[FA_MAXLANES];
     int failed;
 
     /* staging for plain host pointers; hstream[0] / [1]: copy streams of the chunked host pipeline */
@@ -131,6 +135,8 @@ struct fftw_plan_s {
     size_t stage_in_bytes, stage_out_bytes;
 
     double est_flops;
+
+    struct fftw_plan_s *alt;    /* FFTW_UNALIGNED twin, built on the first new-array execution that needs it */
 
     double *prof_ms;            /* fftw_amd_execute_profiled: per-step sinks, NULL otherwise */
     long long *prof_launches;
@@ -159,5 +165,8 @@ int  fa_device_init(struct fftw_plan_s *p);
 void fa_run(struct fftw_plan_s *p, double *ri, double *ii, double *ro, double *io);
 char *fa_sprint(const struct fftw_plan_s *p);
 fa_cfg fa_default_cfg(void);
+
+/* api.c */
+struct fftw_plan_s *fa_unaligned_twin(const struct fftw_plan_s *p);
 
 #endif

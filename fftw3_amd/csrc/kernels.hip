@@ -1051,6 +1051,15 @@ extern "C" int fa_hip_is_device_ptr(const void *p) {
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
+/* ordinal of the device that owns a device allocation, -1 for anything else */
+extern "C" int fa_hip_ptr_device(const void *p) {
+    if (!p || fa_hip_device_count() <= 0) return -1;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged) return -1;
+    return attr.device;
+}
+
 extern "C" void fa_hip_memcpy_h2d(void *dst, const void *src, size_t n, void *stream) {
     FA_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, (hipStream_t)stream));
 }

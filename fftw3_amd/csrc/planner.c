@@ -25,27 +25,49 @@
 typedef struct fftw_plan_s plan;
 
 /* scratch per chunk: what one chunk writes between two passes must still be in the 256 MiB
-   Infinity Cache when the next pass reads it (membw3: 16 transforms of 2^20 best, 64 lose it) */
-#define FA_DEFAULT_CHUNK_BYTES ((size_t)256 << 20)
+   Infinity Cache when the next pass reads it.  Round 3 (tests/micro/mall_probe.hip, profiles/r03_mall_probe.txt):
+   the two-pass 2^20 plan as pure data movement takes 10.0 us per transform as serial launches over 256 MiB
+   chunks, and 8.2 us when chunk c runs on stream c % 2 with 96 ... 128 MiB of scratch per chunk (two lanes,
+   256 MiB of scratch in flight): the tail of one lane's launch is filled by the other lane's, and the
+   reuse distance of a scratch line is a few transforms instead of a whole 1 GiB launch pair. */
+#define FA_DEFAULT_CHUNK_BYTES ((size_t)128 << 20)
+/* The only process-wide planner setting: the documented setter below (read and written atomically).
+   Everything else a plan is built from lives in the plan's own fa_cfg; the FFTW_AMD_* environment
+   overrides are read into that copy at plan creation, never into shared state, so threads that plan
+   with different settings do not see each other's. */
 static size_t g_chunk_bytes = FA_DEFAULT_CHUNK_BYTES;
-static i64 g_lmax_multi = 1024;
-static int g_pipeline = 0;   /* two-stream chunk pipeline: off under FFTW_ESTIMATE (each kernel then owns the machine and
-                                  its launch duration is its roofline), a FFTW_MEASURE candidate, FFTW_AMD_PIPELINE=1 */
-static int g_small_tiles = 1;
-static int g_long_first = 0;
-static i64 g_tile_elems = 0;
 
-void fftw_amd_set_chunk_bytes(size_t nbytes) { g_chunk_bytes = nbytes ? nbytes : FA_DEFAULT_CHUNK_BYTES; }
+void fftw_amd_set_chunk_bytes(size_t nbytes) {
+    __atomic_store_n(&g_chunk_bytes, nbytes ? nbytes : FA_DEFAULT_CHUNK_BYTES, __ATOMIC_RELAXED);
+}
 
 static i64 iabs(i64 v) { return v < 0 ? -v : v; }
 
 fa_cfg fa_default_cfg(void) {
     fa_cfg c;
-    c.chunk_bytes = g_chunk_bytes;
-    c.pipeline = g_pipeline;
-    c.lmax_multi = (int)g_lmax_multi;
-    c.small_tiles = g_small_tiles;
-    c.long_first = g_long_first;
+    const char *e;
+    c.chunk_bytes = __atomic_load_n(&g_chunk_bytes, __ATOMIC_RELAXED);
+    c.pipeline = 0;       /* two-stream chunk pipeline: off under FFTW_ESTIMATE (each kernel then owns the machine and
+                             its launch duration is its roofline), a FFTW_MEASURE candidate, FFTW_AMD_PIPELINE=1 */
+    c.lmax_multi = 1024;
+    c.small_tiles = 1;
+    c.long_first = 0;
+    c.tile_elems = 0;
+    c.lanes = 2;
+    e = getenv("FFTW_AMD_CHUNK_BYTES");
+    if (e && atoll(e) > 0) c.chunk_bytes = (size_t)atoll(e);
+    e = getenv("FFTW_AMD_SMALL_TILES");
+    if (e) c.small_tiles = atoi(e);
+    e = getenv("FFTW_AMD_TILE_ELEMS");
+    if (e) c.tile_elems = atoll(e);
+    e = getenv("FFTW_AMD_LONG_FIRST");
+    if (e) c.long_first = atoi(e);
+    e = getenv("FFTW_AMD_PIPELINE");
+    if (e) c.pipeline = atoi(e);
+    e = getenv("FFTW_AMD_LMAX_MULTI");
+    if (e && atoll(e) >= 16) c.lmax_multi = (int)atoll(e);
+    e = getenv("FFTW_AMD_LANES");
+    if (e && atoi(e) >= 1 && atoi(e) <= FA_MAXLANES) c.lanes = atoi(e);
     return c;
 }
 
@@ -53,22 +75,9 @@ fa_cfg fa_default_cfg(void) {
 
 plan *fa_plan_new(void) {
     plan *p = (plan *)calloc(1, sizeof(plan));
-    const char *e;
     if (!p) return NULL;
     p->nbufs = 2;
     p->in_im = p->out_im = 1;
-    e = getenv("FFTW_AMD_CHUNK_BYTES");
-    if (e && atoll(e) > 0) g_chunk_bytes = (size_t)atoll(e);
-    e = getenv("FFTW_AMD_SMALL_TILES");
-    if (e) g_small_tiles = atoi(e);
-    e = getenv("FFTW_AMD_TILE_ELEMS");
-    if (e) g_tile_elems = atoll(e);
-    e = getenv("FFTW_AMD_LONG_FIRST");
-    if (e) g_long_first = atoi(e);
-    e = getenv("FFTW_AMD_PIPELINE");
-    if (e) g_pipeline = atoi(e);
-    e = getenv("FFTW_AMD_LMAX_MULTI");
-    if (e && atoll(e) >= 16) g_lmax_multi = atoll(e);
     p->cfg = fa_default_cfg();
     pthread_mutex_init(&p->lock, NULL);
     return p;
@@ -92,6 +101,7 @@ static void plan_reset_build(plan *p) {
 void fa_plan_free(plan *p) {
     int i;
     if (!p) return;
+    if (p->alt) { fa_plan_free(p->alt); p->alt = NULL; }
     {
         /* device resources may exist without dev_ready (fa_device_init gave up half way: out of device memory) */
         int any = p->dev_ready || p->stage_in || p->stage_out || p->hstream[0] || p->pstream[0];
@@ -108,12 +118,12 @@ void fa_plan_free(plan *p) {
         if (p->hstream[0]) fa_hip_stream_destroy(p->hstream[0]);
         if (p->hstream[1]) fa_hip_stream_destroy(p->hstream[1]);
         if (p->pstream[0]) {
-            for (i = 0; i < 4; ++i) { fa_hip_event_destroy(p->ev_a[i]); fa_hip_event_destroy(p->ev_b[i]); }
+            for (i = 0; i < 4; ++i) { if (p->ev_a[i]) fa_hip_event_destroy(p->ev_a[i]); if (p->ev_b[i]) fa_hip_event_destroy(p->ev_b[i]); }
             fa_hip_event_destroy(p->ev_begin);
-            fa_hip_event_destroy(p->ev_end[0]);
-            fa_hip_event_destroy(p->ev_end[1]);
-            fa_hip_stream_destroy(p->pstream[0]);
-            fa_hip_stream_destroy(p->pstream[1]);
+            for (i = 0; i < FA_MAXLANES; ++i) {
+                if (p->ev_end[i]) fa_hip_event_destroy(p->ev_end[i]);
+                if (p->pstream[i]) fa_hip_stream_destroy(p->pstream[i]);
+            }
         }
     }
 host_only:
@@ -432,7 +442,7 @@ static void emit_pass(plan *p, fa_loc src, fa_loc dst, i64 L, i64 is_l, i64 os_l
        sequences (128-byte segments).  small_tiles = 0 (a FFTW_MEASURE candidate) keeps
        the 4096-element tiles.  The register kernels set their own tile below. */
     {
-        i64 elems = g_tile_elems > 0 ? g_tile_elems : (p->cfg.small_tiles ? 1024 : FA_TILE_ELEMS);
+        i64 elems = p->cfg.tile_elems > 0 ? p->cfg.tile_elems : (p->cfg.small_tiles ? 1024 : FA_TILE_ELEMS);
         i64 cap = elems / L, floor_t = (iabs(is_l) <= 2 && iabs(os_l) <= 2) ? 1 : 8;
         if (cap < floor_t) cap = floor_t;
         if (T > cap) T = cap;
@@ -1030,7 +1040,12 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
        such a length works on tiles of 4 ... 7 columns (64 ... 112-byte segments, ~3.2 TB/s) -- slower per trip
        than the 128-byte kernels, but two trips beat three (2^21 = 2048 x 1024: 7.9 vs 11.2 ms per 8 GiB; with
        BOTH lengths above 1024 the two slow trips only tie with three fast ones, so that is not done) */
-    if (k == 3 && contiguous && ax.nloops > 0 && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_NARROW")) {
+    /* (the narrow-tile kernel takes interleaved complex data on 16-byte aligned arrays only -- the same
+       conditions as for a strided axis above; with split or unaligned arrays its pass would fall to the
+       runtime-radix LDS kernel with a 1 ... 2 column tile, far slower than the three-pass plan) */
+    if (k == 3 && contiguous && ax.nloops > 0 && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_NARROW") &&
+        ax.src.im == 1 && ax.dst.im == 1 && !(p->flags & FFTW_UNALIGNED) && p->cfg.lmax_multi >= 1024 &&
+        !((ax.flags_in | ax.flags_out) & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT))) {
         /* cost per GiB of a pass (the units of split_costs.inc): narrow-tile first pass 0.34 (2048-point: 5.33 ms
            per 16 GiB), the partner as LAST pass from the table (1024: 0.18, the cfg2 pass; 1000: 0.20); the
            three-pass alternative from the same table (powers of two: 0.68, measured 2^21 ... 2^24) */
@@ -1050,7 +1065,10 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
         }
         if (bestL1 && best2 < 0.95 * est3) { k = 2; lens[0] = bestL1; lens[1] = ax.n / bestL1; }
     }
-    if (k == 3 && contiguous && (ax.n & (ax.n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) pow2_three_pass_split(ax.n, lens);
+    /* the measured split models know lengths up to 1024: with a smaller cap (the FFTW_MEASURE candidate
+       lmax_multi = 512, FFTW_AMD_LMAX_MULTI) the balanced split of fa_factor_passes_pref, which honours it, stays */
+    if (p->cfg.lmax_multi < 1024) { /* keep lens */ }
+    else if (k == 3 && contiguous && (ax.n & (ax.n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) pow2_three_pass_split(ax.n, lens);
     else if (k == 3 && contiguous && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_SPLIT_COSTS")) mixed_three_pass_split(ax.n, lens);
     else if (k == 2 && contiguous && ax.nloops > 0 && lens[0] <= 1024 && lens[1] <= 1024 && !getenv("FFTW_AMD_NO_TUNED") &&
              !getenv("FFTW_AMD_NO_SPLIT_COSTS")) mixed_two_pass_split(ax.n, lens);
@@ -1187,21 +1205,21 @@ static void build_c2c(plan *p) {
 
 /* passes a contiguous axis of length n needs (mirrors fa_emit_axis); 99 for
    lengths that go through Rader / Bluestein */
-static int axis_pass_count(i64 n) {
+static int axis_pass_count(const plan *p, i64 n) {
     i64 lens[FA_MAXPASS], lmax1 = FA_LMAX_SINGLE;
     int k;
     if (!fa_lds_able(n)) return 99;
     /* (the radix-4 real plans feed strided pair data: the 3-stage row kernel does not apply) */
     if (n > 1024 && (n & (n - 1)) == 0 && !getenv("FFTW_AMD_NO_TUNED")) lmax1 = 1024;
-    k = fa_factor_passes(n, FA_MAXPASS, lmax1, g_lmax_multi, lens);
+    k = fa_factor_passes(n, FA_MAXPASS, lmax1, p->cfg.lmax_multi, lens);
     return k ? k : 99;
 }
 
 /* passes of the half-length complex transform of an r2c / c2r axis: its rows are contiguous, so a length with
    a three-stage rows kernel (up to 8192) is one pass */
-static int half_axis_pass_count(i64 n) {
+static int half_axis_pass_count(const plan *p, i64 n) {
     if (n <= 16384 && !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_3S") && fa_hip_r3_tile((int)n) > 0) return 1;
-    return axis_pass_count(n);
+    return axis_pass_count(p, n);
 }
 
 /* r2c: last dim real -> half spectrum, then complex DFTs over the other dims
@@ -1330,7 +1348,7 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
     int j;
     if (ps == 0) { ps = 2 * rs; pim = rs; }
     if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
-        (axis_pass_count(nl / 4) < half_axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
+        (axis_pass_count(p, nl / 4) < half_axis_pass_count(p, nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
         /* n = 4m: two complex DFTs of size m on (x[4j], x[4j+1]) and (x[4j+2], x[4j+3]),
            then the radix-4 untangle -- the reference's rdft2-ct-dit/4 + hc2cfdft_4 plan,
            chosen when m needs fewer passes than n/2 (n = 2^22: m = 2^20 is 1024 x 1024) */
@@ -1526,7 +1544,7 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
     int j;
     if (ps == 0) { ps = 2 * rs; pim = rs; }
     if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
-        (axis_pass_count(nl / 4) < half_axis_pass_count(nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
+        (axis_pass_count(p, nl / 4) < half_axis_pass_count(p, nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
         /* transpose of the radix-4 r2c plan: tangle into two quarter-length
            spectra, two backward complex DFTs of size m straight into the real array */
         i64 m = nl / 4, zts, lts[FA_MAXLOOPS + 1], total;
@@ -2135,7 +2153,7 @@ int fa_device_init(plan *p) {
         /* batched 1024 x 1024: pass 2 of chunk c-1 and pass 1 of chunk c share a launch (two scratch slots) */
         static int pair_mode = -1;     /* FFTW_AMD_PAIR=0 switches it off */
         if (pair_mode < 0) { const char *e = getenv("FFTW_AMD_PAIR"); pair_mode = e ? atoi(e) : 1; }
-        if (pair_mode && !p->cfg.pipeline && p->nsteps == 2 && p->nbufs == 3 && p->chunk > 0 && p->chunk < p->batch &&
+        if (pair_mode && !p->cfg.pipeline && p->cfg.lanes <= 1 && p->nsteps == 2 && p->nbufs == 3 && p->chunk > 0 && p->chunk < p->batch &&
             !p->single_chunk &&
             p->steps[0].kind == FFTW_AMD_STEP_PASS && p->steps[1].kind == FFTW_AMD_STEP_PASS &&
             p->steps[0].variant == FFTW_AMD_K_P1024 && p->steps[1].variant == FFTW_AMD_K_P1024 &&
@@ -2161,6 +2179,24 @@ int fa_device_init(plan *p) {
             p->ev_end[0] = fa_hip_event_create();
             p->ev_end[1] = fa_hip_event_create();
         }
+    }
+    /* chunk lanes: chunk c runs all its steps, in order, on stream c % lanes in scratch slot c % lanes; the
+       lanes share the machine, so the tail of one lane's launch overlaps the other lane's next launch and
+       no dependency crosses the lanes */
+    p->lanes = 1;
+    if (!p->pair && p->nslots == 1 && p->cfg.lanes > 1 && p->chunk > 0 && p->nsteps >= 2 && p->nbufs > 2 &&
+        !p->single_chunk && (p->batch + p->chunk - 1) / p->chunk >= 2) {
+        i64 nch = (p->batch + p->chunk - 1) / p->chunk, per = 0;
+        for (i = 2; i < p->nbufs; ++i) per += p->buf_reals[i];
+        /* a chunk whose scratch is beyond the budget anyway (one transform of hundreds of MB: nothing stays in
+           the Infinity Cache whatever the order) gains nothing from a second lane and loses a little to the
+           doubled footprint (cfg4, n = 15 375 360: 68.5 ms serial, 69 ... 75 ms with two lanes) */
+        if ((size_t)per * sizeof(double) > p->cfg.chunk_bytes) nch = 0;
+        p->lanes = p->cfg.lanes > FA_MAXLANES ? FA_MAXLANES : p->cfg.lanes;
+        if (p->lanes > nch) p->lanes = nch > 0 ? (int)nch : 1;
+        p->nslots = p->lanes;
+        for (i = 0; p->lanes > 1 && i < p->lanes; ++i) { p->pstream[i] = fa_hip_stream_create(); p->ev_end[i] = fa_hip_event_create(); }
+        if (p->lanes > 1) p->ev_begin = fa_hip_event_create();
     }
     for (i = 2; i < p->nbufs; ++i)
         if (!p->dbuf[i]) {
@@ -2242,6 +2278,20 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
    reference (A.c:433, re-entrant executors) but here they share scratch and streams */
 void fa_run(plan *p, double *ri, double *ii, double *ro, double *io) {
     pthread_mutex_lock(&p->lock);
+    /* New-array execution on arrays aligned differently from the plan's own (a caller error by FFTW's rules,
+       fftw3.h "new-array execute"): the plan may hold steps whose kernels rely on the 16-byte alignment it
+       saw at planning time and have no other executor.  Run the FFTW_UNALIGNED twin instead -- same problem,
+       same tables' values, only kernels that serve every alignment -- rather than abort() inside a library. */
+    if (!(p->flags & FFTW_UNALIGNED) && p->ri && p->ro && p->batch > 0 &&
+        ((((size_t)ri ^ (size_t)p->ri) | ((size_t)ii ^ (size_t)p->ii) | ((size_t)ro ^ (size_t)p->ro) | ((size_t)io ^ (size_t)p->io)) & 15)) {
+        if (!p->alt) p->alt = fa_unaligned_twin(p);
+        if (p->alt) {
+            p->alt->stream = p->stream;
+            fa_run_locked(p->alt, ri, ii, ro, io);
+            pthread_mutex_unlock(&p->lock);
+            return;
+        }
+    }
     fa_run_locked(p, ri, ii, ro, io);
     pthread_mutex_unlock(&p->lock);
 }
@@ -2293,7 +2343,7 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
        chunk c and download of chunk c-1 overlap, so an unmodified host caller sees max(H2D, D2H) of the PCIe
        link instead of their sum plus the compute.  Everything else is staged whole, as before. */
     if (in_host && out_host && !host_inplace && !Lin.two && !Lout.two && p->hrank == 1 && !p->prof_ms &&
-        p->chunk > 0 && p->chunk < p->batch && !p->single_chunk && !(p->nslots > 1 && p->pstream[0])) {
+        p->chunk > 0 && p->chunk < p->batch && !p->single_chunk && !(p->nslots > 1 && p->pstream[0] && p->lanes <= 1)) {
         const i64 B = p->batch, ibs = p->hdims[0].is, obs = p->hdims[0].os;
         const i64 it_span = Lin.span - (B - 1) * ibs, ot_span = Lout.span - (B - 1) * obs;   /* one transform's span */
         static int hp_mode = -1;        /* FFTW_AMD_HOST_PIPELINE=0 switches it off */
@@ -2395,25 +2445,28 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
     if (!p->pair) {
         i64 nchunks = (p->batch + p->chunk - 1) / p->chunk, ev = 0, c = 0;
         void **events = NULL;
-        const int pipe = p->nslots > 1 && p->pstream[0];
+        const int pipe = p->nslots > 1 && p->pstream[0] && p->lanes <= 1;
+        /* profiled executions run the lanes one after the other on the caller's stream (slot 0), so that the
+           HIP events around a launch time that launch alone */
+        const int lanes = (p->lanes > 1 && !p->prof_ms) ? p->lanes : 1;
         if (p->prof_ms) events = (void **)malloc(sizeof(void *) * (size_t)(2 * nchunks * p->nsteps));
-        if (pipe) {
+        if (pipe || lanes > 1) {
             /* the side streams start after everything already queued on the caller's stream */
             fa_hip_event_record(p->ev_begin, p->stream);
-            fa_hip_stream_wait_event(p->pstream[0], p->ev_begin);
-            fa_hip_stream_wait_event(p->pstream[1], p->ev_begin);
+            for (i = 0; i < (pipe ? 2 : lanes); ++i) fa_hip_stream_wait_event(p->pstream[i], p->ev_begin);
         }
         for (cs = 0; cs < p->batch; cs += p->chunk, ++c) {
             i64 cn = p->batch - cs < p->chunk ? p->batch - cs : p->chunk;
             double *sb[FA_MAXBUF];
-            int slot = pipe ? (int)(c % p->nslots) : 0;
+            int slot = pipe ? (int)(c % p->nslots) : (lanes > 1 ? (int)(c % lanes) : 0);
+            void *lane_st = lanes > 1 ? p->pstream[c % lanes] : p->stream;
             sb[0] = bufs[0];
             sb[1] = bufs[1];
             for (i = 2; i < p->nbufs; ++i) sb[i] = bufs[i] + (i64)slot * p->buf_reals[i];
-            if (hpipe) fa_hip_stream_wait_event(p->stream, ev_in[c]);
+            if (hpipe) fa_hip_stream_wait_event(lane_st, ev_in[c]);
             for (i = 0; i < p->nsteps; ++i) {
                 fftw_amd_step_desc d = p->steps[i];
-                void *st = p->stream;
+                void *st = lane_st;
                 if (pipe) {
                     st = p->pstream[i < p->split ? 0 : 1];
                     /* stage A reuses a slot only after stage B of its previous user is done */
@@ -2432,17 +2485,17 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
             if (hpipe && !ev_out[c]) {
                 const i64 lo = Lout.lo + cs * hp_obs, len = (cn - 1) * hp_obs + hp_ospan;
                 ev_out[c] = fa_hip_event_create();
-                fa_hip_event_record(ev_out[c], p->stream);
+                fa_hip_event_record(ev_out[c], lane_st);
                 fa_hip_stream_wait_event(p->hstream[1], ev_out[c]);
                 fa_hip_memcpy_d2h(ro + lo, dout + lo, (size_t)len * sizeof(double), p->hstream[1]);
             }
         }
-        if (pipe) {
-            /* the caller's stream continues after both side streams have drained */
-            fa_hip_event_record(p->ev_end[0], p->pstream[0]);
-            fa_hip_event_record(p->ev_end[1], p->pstream[1]);
-            fa_hip_stream_wait_event(p->stream, p->ev_end[0]);
-            fa_hip_stream_wait_event(p->stream, p->ev_end[1]);
+        if (pipe || lanes > 1) {
+            /* the caller's stream continues after the side streams have drained */
+            for (i = 0; i < (pipe ? 2 : lanes); ++i) {
+                fa_hip_event_record(p->ev_end[i], p->pstream[i]);
+                fa_hip_stream_wait_event(p->stream, p->ev_end[i]);
+            }
         }
         if (events) {
             fa_hip_stream_sync(p->stream);

@@ -49,8 +49,7 @@ struct fftw_amd_sharded_plan_s {
     int dense_out;
     shard_worker w[FA_MAXDEV];
     void *const *gather_dst;       /* argument of the pending CMD_GATHER */
-    /* RCCL, when used */
-    void *rccl_lib;
+    /* RCCL, when used (the library itself is process-wide: g_nccl) */
     void *comms[FA_MAXDEV];
     int rccl_ready;
 };
@@ -172,7 +171,7 @@ static struct fftw_amd_sharded_plan_s *mk_sharded(int type, int rank, const int 
                                                  void *const *out, const int *onembed, int ostride, int odist,
                                                  int sign, unsigned flags) {
     struct fftw_amd_sharded_plan_s *p;
-    int g, i;
+    int g, i, ndevices, saved_dev;
     long long out_elems = 1;
     if (ndev < 1 || ndev > FA_MAXDEV || !in || !out || howmany < 0 || rank < 1 || !n) return NULL;
     p = (struct fftw_amd_sharded_plan_s *)calloc(1, sizeof(*p));
@@ -186,15 +185,29 @@ static struct fftw_amd_sharded_plan_s *mk_sharded(int type, int rank, const int 
     p->out_dist_bytes = (long long)odist * (type == FA_C2R ? 8 : 16);
     p->out_elem_bytes = (size_t)out_elems * (size_t)ostride * (type == FA_C2R ? 8 : 16);
     p->dense_out = odist > 0 && (long long)p->out_elem_bytes <= p->out_dist_bytes;
+    ndevices = fa_hip_device_count();
+    saved_dev = ndevices > 0 ? fa_hip_get_device() : -1;
+    for (g = 0; g < ndev; ++g) {
+        p->devs[g] = devs ? devs[g] : g;
+        /* with a device runtime present every named device must exist (without one the plan can
+           still be built and inspected: the CPU test tier does) */
+        if (ndevices > 0 && (p->devs[g] < 0 || p->devs[g] >= ndevices)) {
+            fprintf(stderr, "fftw3_amd: sharded plan names device %d, but only %d are visible\n", p->devs[g], ndevices);
+            free(p);
+            return NULL;
+        }
+    }
     for (g = 0; g < ndev; ++g) {
         long long cnt;
-        p->devs[g] = devs ? devs[g] : g;
         fftw_amd_shard_range(howmany, ndev, g, &p->lo[g], &p->hi[g]);
         cnt = p->hi[g] - p->lo[g];
         p->in[g] = in[g]; p->out[g] = out[g];
         if (cnt <= 0) continue;
-        if (!in[g] || !out[g]) { fftw_amd_destroy_sharded_plan(p); return NULL; }
-        /* the replica is an ordinary plan of this library over the shard's own batch */
+        if (!in[g] || !out[g]) { if (saved_dev >= 0) fa_hip_set_device(saved_dev); fftw_amd_destroy_sharded_plan(p); return NULL; }
+        /* the replica is an ordinary plan of this library over the shard's own batch.  A plan puts its
+           tables and scratch on the CURRENT device when it is created (api.c finish_locked ->
+           fa_device_init) and FFTW_MEASURE times candidates there: make that the shard's device */
+        if (saved_dev >= 0) fa_hip_set_device(p->devs[g]);
         if (type == FA_R2C)
             p->replica[g] = fftw_plan_many_dft_r2c(rank, n, (int)cnt, (double *)in[g], inembed, istride, idist,
                                                    (fftw_complex *)out[g], onembed, ostride, odist, flags);
@@ -204,8 +217,9 @@ static struct fftw_amd_sharded_plan_s *mk_sharded(int type, int rank, const int 
         else
             p->replica[g] = fftw_plan_many_dft(rank, n, (int)cnt, (fftw_complex *)in[g], inembed, istride, idist,
                                                (fftw_complex *)out[g], onembed, ostride, odist, sign, flags);
-        if (!p->replica[g]) { fftw_amd_destroy_sharded_plan(p); return NULL; }
+        if (!p->replica[g]) { if (saved_dev >= 0) fa_hip_set_device(saved_dev); fftw_amd_destroy_sharded_plan(p); return NULL; }
     }
+    if (saved_dev >= 0) fa_hip_set_device(saved_dev);
     return p;
 }
 
@@ -254,14 +268,58 @@ void fftw_amd_sharded_sync(const fftw_amd_sharded_plan p) {
     if (any) broadcast_cmd(p, CMD_SYNC);
 }
 
-/* ---- RCCL, loaded on first use: only the five entry points the gather needs ---- */
+/* ---- RCCL, loaded once per process: only the entry points the gather needs ---- */
 typedef int (*nccl_init_all_fn)(void **comms, int ndev, const int *devlist);
 typedef int (*nccl_destroy_fn)(void *comm);
 typedef int (*nccl_group_fn)(void);
 typedef int (*nccl_bcast_fn)(const void *send, void *recv, size_t count, int dtype, int root, void *comm, void *stream);
+typedef int (*nccl_allgather_fn)(const void *send, void *recv, size_t sendcount, int dtype, void *comm, void *stream);
 typedef const char *(*nccl_errstr_fn)(int);
-static struct { nccl_init_all_fn init_all; nccl_destroy_fn destroy; nccl_group_fn gstart, gend; nccl_bcast_fn bcast; nccl_errstr_fn errstr; } g_nccl;
+static struct {
+    void *lib;
+    nccl_init_all_fn init_all; nccl_destroy_fn destroy; nccl_group_fn gstart, gend; nccl_bcast_fn bcast;
+    nccl_allgather_fn allgather; nccl_errstr_fn errstr;
+    int nsyms;          /* entry points resolved */
+    int ok;
+} g_nccl;
+static pthread_once_t g_nccl_once = PTHREAD_ONCE_INIT;
 #define FA_NCCL_INT8 0     /* ncclInt8 / ncclChar: the gather moves opaque bytes */
+#define FA_NCCL_NSYMS 7
+
+/* The library is opened once and stays open for the life of the process (plans share the table; a
+   dlclose while another plan's communicators are alive would pull the code from under them).
+   FFTW_AMD_RCCL_LIB names another library with the same entry points (the CPU test tier uses a
+   recording mock). */
+static void rccl_load_once(void) {
+    const char *over = getenv("FFTW_AMD_RCCL_LIB");
+    void *h = NULL;
+    if (over && *over) h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    else {
+        h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!h) return;
+    g_nccl.init_all = (nccl_init_all_fn)dlsym(h, "ncclCommInitAll");
+    g_nccl.destroy = (nccl_destroy_fn)dlsym(h, "ncclCommDestroy");
+    g_nccl.gstart = (nccl_group_fn)dlsym(h, "ncclGroupStart");
+    g_nccl.gend = (nccl_group_fn)dlsym(h, "ncclGroupEnd");
+    g_nccl.bcast = (nccl_bcast_fn)dlsym(h, "ncclBroadcast");
+    g_nccl.allgather = (nccl_allgather_fn)dlsym(h, "ncclAllGather");
+    g_nccl.errstr = (nccl_errstr_fn)dlsym(h, "ncclGetErrorString");
+    g_nccl.nsyms = !!g_nccl.init_all + !!g_nccl.destroy + !!g_nccl.gstart + !!g_nccl.gend + !!g_nccl.bcast +
+                   !!g_nccl.allgather + !!g_nccl.errstr;
+    if (g_nccl.nsyms != FA_NCCL_NSYMS) { dlclose(h); return; }
+    g_nccl.lib = h;
+    g_nccl.ok = 1;
+}
+
+/* number of RCCL entry points the loader resolved (7 when the gather can use RCCL, 0 when the
+   library cannot be opened); opens the library but makes no RCCL call */
+int fftw_amd_rccl_probe(void) {
+    pthread_once(&g_nccl_once, rccl_load_once);
+    return g_nccl.ok ? g_nccl.nsyms : 0;
+}
 
 static int rccl_setup(struct fftw_amd_sharded_plan_s *p) {
     int g, h, rc;
@@ -270,25 +328,53 @@ static int rccl_setup(struct fftw_amd_sharded_plan_s *p) {
     for (g = 0; g < p->ndev; ++g)
         for (h = 0; h < g; ++h)
             if (p->devs[g] == p->devs[h]) return -1;       /* RCCL wants one rank per device */
-    p->rccl_lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!p->rccl_lib) p->rccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!p->rccl_lib) p->rccl_lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!p->rccl_lib) return -1;
-    g_nccl.init_all = (nccl_init_all_fn)dlsym(p->rccl_lib, "ncclCommInitAll");
-    g_nccl.destroy = (nccl_destroy_fn)dlsym(p->rccl_lib, "ncclCommDestroy");
-    g_nccl.gstart = (nccl_group_fn)dlsym(p->rccl_lib, "ncclGroupStart");
-    g_nccl.gend = (nccl_group_fn)dlsym(p->rccl_lib, "ncclGroupEnd");
-    g_nccl.bcast = (nccl_bcast_fn)dlsym(p->rccl_lib, "ncclBroadcast");
-    g_nccl.errstr = (nccl_errstr_fn)dlsym(p->rccl_lib, "ncclGetErrorString");
-    if (!g_nccl.init_all || !g_nccl.destroy || !g_nccl.gstart || !g_nccl.gend || !g_nccl.bcast) return -1;
+    pthread_once(&g_nccl_once, rccl_load_once);
+    if (!g_nccl.ok) return -1;
     rc = g_nccl.init_all(p->comms, p->ndev, p->devs);
     if (rc != 0) {
-        fprintf(stderr, "fftw3_amd: ncclCommInitAll failed (%s); the gather uses peer-to-peer copies\n",
-                g_nccl.errstr ? g_nccl.errstr(rc) : "?");
+        fprintf(stderr, "fftw3_amd: ncclCommInitAll failed (%s); the gather uses peer-to-peer copies\n", g_nccl.errstr(rc));
+        memset(p->comms, 0, sizeof(p->comms));
         return -1;
     }
     p->rccl_ready = 1;
     return 0;
+}
+
+/* The RCCL calls of one gather, in issue order (all inside ONE group).  Equal shards (the common
+   case: ndev divides howmany): one ncclAllGather per rank, in place when the shard already sits at
+   its slot of the image.  Ragged tails of the block rule (the last shards shorter or empty) cannot
+   be expressed with equal counts: one ncclBroadcast per non-empty shard and rank instead.
+   Each op is 6 values: kind (0 all-gather, 1 broadcast), rank d, root g (-1 for all-gather),
+   send pointer, receive pointer, bytes.  Returns the number of ops (computed even if cap is short). */
+int fftw_amd_sharded_gather_ops(const fftw_amd_sharded_plan p, void *const *full, long long *ops, int cap) {
+    int g, d, n = 0, equal = 1;
+    if (!p || !full) return -1;
+    for (g = 1; g < p->ndev; ++g)
+        if (p->hi[g] - p->lo[g] != p->hi[0] - p->lo[0]) equal = 0;
+    if (p->hi[0] - p->lo[0] <= 0) equal = 0;
+    if (equal) {
+        const long long bytes = (p->hi[0] - p->lo[0]) * p->out_dist_bytes;
+        for (d = 0; d < p->ndev; ++d, ++n) {
+            if (n >= cap) continue;
+            ops[6 * n + 0] = 0; ops[6 * n + 1] = d; ops[6 * n + 2] = -1;
+            ops[6 * n + 3] = (long long)(size_t)p->out[d];
+            ops[6 * n + 4] = (long long)(size_t)full[d];
+            ops[6 * n + 5] = bytes;
+        }
+        return n;
+    }
+    for (g = 0; g < p->ndev; ++g) {
+        const long long bytes = (p->hi[g] - p->lo[g]) * p->out_dist_bytes;
+        if (bytes <= 0) continue;
+        for (d = 0; d < p->ndev; ++d, ++n) {
+            if (n >= cap) continue;
+            ops[6 * n + 0] = 1; ops[6 * n + 1] = d; ops[6 * n + 2] = g;
+            ops[6 * n + 3] = (long long)(size_t)p->out[g];       /* read on the root only */
+            ops[6 * n + 4] = (long long)(size_t)((char *)full[d] + (size_t)p->lo[g] * (size_t)p->out_dist_bytes);
+            ops[6 * n + 5] = bytes;
+        }
+    }
+    return n;
 }
 
 /* Reassemble the output: full[d] is a device buffer on shard d's device with room for all `howmany`
@@ -302,23 +388,28 @@ int fftw_amd_sharded_all_gather(const fftw_amd_sharded_plan p, void *const *full
     if (p->howmany == 0) return 0;
     if (start_workers(p)) return -1;
     if (mode != 1 && rccl_setup(p) == 0) {
-        /* one broadcast per shard inside a group: the shards of the block rule may differ in size,
-           which ncclAllGather (equal counts) cannot express */
-        int cur = fa_hip_get_device(), rc = 0;
-        broadcast_cmd(p, CMD_SYNC);                     /* RCCL runs on the same streams: keep it simple, drain first */
+        /* Rank d's calls go on stream[d], the stream shard d's transforms were enqueued on
+           (fftw_amd_execute_sharded returns after every worker has enqueued): each rank's part of
+           the collective is ordered behind its own transforms by the stream, and the collective
+           itself makes the receivers wait for the senders -- no host-side drain. */
+        long long ops[6 * FA_MAXDEV * FA_MAXDEV];
+        const int nops = fftw_amd_sharded_gather_ops(p, full, ops, FA_MAXDEV * FA_MAXDEV);
+        int cur = fa_hip_get_device(), rc = 0, k;
         rc |= g_nccl.gstart();
-        for (g = 0; g < p->ndev; ++g) {
-            size_t bytes = (size_t)(p->hi[g] - p->lo[g]) * (size_t)p->out_dist_bytes;
-            if (!bytes) continue;
-            for (d = 0; d < p->ndev; ++d) {
-                char *dst = (char *)full[d] + (size_t)p->lo[g] * (size_t)p->out_dist_bytes;
-                fa_hip_set_device(p->devs[d]);
-                rc |= g_nccl.bcast(p->out[g], dst, bytes, FA_NCCL_INT8, g, p->comms[d], p->stream[d]);
-            }
+        for (k = 0; k < nops; ++k) {
+            const long long *o = ops + 6 * k;
+            d = (int)o[1];
+            fa_hip_set_device(p->devs[d]);
+            if (o[0] == 0)
+                rc |= g_nccl.allgather((const void *)(size_t)o[3], (void *)(size_t)o[4], (size_t)o[5], FA_NCCL_INT8,
+                                       p->comms[d], p->stream[d]);
+            else
+                rc |= g_nccl.bcast((const void *)(size_t)o[3], (void *)(size_t)o[4], (size_t)o[5], FA_NCCL_INT8, (int)o[2],
+                                   p->comms[d], p->stream[d]);
         }
         rc |= g_nccl.gend();
         fa_hip_set_device(cur);
-        if (rc != 0) { fprintf(stderr, "fftw3_amd: RCCL gather failed (%s)\n", g_nccl.errstr ? g_nccl.errstr(rc) : "?"); return -1; }
+        if (rc != 0) { fprintf(stderr, "fftw3_amd: RCCL gather failed (%s)\n", g_nccl.errstr(rc)); return -1; }
         return 1;
     }
     if (mode == 2) return -1;
@@ -347,7 +438,7 @@ void fftw_amd_destroy_sharded_plan(fftw_amd_sharded_plan p) {
         pthread_mutex_destroy(&w->mu);
         pthread_cond_destroy(&w->cv);
     }
-    if (p->rccl_ready > 0)
+    if (p->rccl_ready > 0 && g_nccl.ok)
         for (g = 0; g < p->ndev; ++g) if (p->comms[g]) g_nccl.destroy(p->comms[g]);
     for (g = 0; g < p->ndev; ++g) {
         if (p->replica[g]) {

@@ -43,6 +43,9 @@ void fftw_amd_plan_sync(fftw_plan p);
 
 /* Bytes of device scratch the plan owns (twiddle tables + work buffers). */
 size_t fftw_amd_plan_workspace_bytes(const fftw_plan p);
+/* Device that holds them: a plan belongs to the device that was current (fftw_amd_set_device / hipSetDevice)
+   when its planner function ran.  -1: none yet / no device; -2: allocations on more than one device (a bug). */
+int fftw_amd_plan_workspace_device(const fftw_plan p);
 
 /* Upper bound, in bytes, for the scratch that one chunk of a multi-pass plan may occupy (default
    256 MiB).  Measured on MI355X: with the caller's input and output streamed with nontemporal
@@ -87,12 +90,21 @@ void fftw_amd_sharded_sync(const fftw_amd_sharded_plan p);
 /* All-gather of the output shards over xGMI: full[d] is a buffer on shard d's device for the
    WHOLE batch (howmany * odist elements); every shard's output lands at its place in each of
    them, ordered after the transforms (complete after fftw_amd_sharded_sync).  mode 0: RCCL
-   (librccl.so, loaded on first use; one ncclBroadcast per shard in a group, because block-rule
-   shards may differ in size) when every shard has its own device, direct peer-to-peer pushes
+   (librccl.so, loaded once per process; ncclAllGather when the shards are equal, one ncclBroadcast per
+   shard in a group when the block rule leaves a ragged tail; issued on the shards' own streams behind
+   their transforms, no host-side drain) when every shard has its own device, direct peer-to-peer pushes
    otherwise; 1: force peer-to-peer; 2: RCCL or fail.  Returns 1 if RCCL moved the data, 0 for
    peer-to-peer, -1 on error.  This is the xGMI-bound part (for cfg5 each GPU
    receives 120 GB at <= 7 x 153 GB/s) and is never part of a transform's timing. */
 int fftw_amd_sharded_all_gather(const fftw_amd_sharded_plan p, void *const *full, int mode);
+/* The RCCL calls fftw_amd_sharded_all_gather issues (inside one group), without issuing them: 6 values per
+   call -- kind (0 ncclAllGather, 1 ncclBroadcast), rank d, root (-1 for all-gather), send pointer, receive
+   pointer, bytes.  Equal shards: one ncclAllGather per rank; ragged block-rule tails: one ncclBroadcast per
+   non-empty shard and rank.  Returns the number of calls (ops holds at most cap of them), -1 on bad arguments. */
+int fftw_amd_sharded_gather_ops(const fftw_amd_sharded_plan p, void *const *full, long long *ops, int cap);
+/* Number of RCCL entry points the loader resolves (7 when librccl.so can serve the gather, else 0); opens the
+   library once per process, makes no RCCL call.  FFTW_AMD_RCCL_LIB names a stand-in library. */
+int fftw_amd_rccl_probe(void);
 
 int  fftw_amd_sharded_num_shards(const fftw_amd_sharded_plan p);
 int  fftw_amd_sharded_device(const fftw_amd_sharded_plan p, int g);

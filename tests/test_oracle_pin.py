@@ -124,3 +124,52 @@ def test_oracle_vs_numpy_crosscheck_and_real():
         assert aerror(y, np.fft.rfft(xr)) < 1e-13
         assert y[0].imag == 0.0 and (n % 2 or y[n // 2].imag == 0.0)   # A.c:7155-7156
         assert aerror(oracle_c2r(y, (n,)), xr * n) < 1e-13
+
+
+def _pins2():
+    return np.load(os.path.join(GOLD, "pins2.npz"))
+
+
+def test_oracle_matches_second_golden_set():
+    """round 3 pins (tests/golden/make_golden2.py: defining sums in 80-bit long double, verifier inputs):
+    Rader 65537 / 12289, Bluestein 8191, 13-smooth 60060 (sampled bins), odd-length r2c / c2r, 3-D c2c and
+    r2c, and every r2r kind at an even and an odd length -- the sizes that until now were only checked
+    oracle-vs-GPU"""
+    from util import oracle_r2r
+    z = _pins2()
+    for n in (65537, 12289, 8191, 60060):
+        x, bins = z["c%d_in" % n], z["c%d_bins" % n]
+        scale = np.abs(z["c%d_fwd" % n]).max()
+        assert np.abs(oracle_dft(x, (n,), 1, -1)[bins] - z["c%d_fwd" % n]).max() < 1e-13 * scale, n
+        assert np.abs(oracle_dft(x, (n,), 1, +1)[bins] - z["c%d_bwd" % n]).max() < 1e-13 * scale, n
+    for n in (77, 1001):
+        x, y = z["r%d_in" % n], z["r%d_out" % n]
+        assert aerror(oracle_r2c(x, (n,)), y) < 1e-13, n
+        assert aerror(oracle_c2r(y, (n,)), x * n) < 1e-13, n
+    for key in ("6x10x8", "5x6x7"):
+        shape = tuple(int(v) for v in key.split("x"))
+        assert aerror(oracle_dft(z["c3_%s_in" % key], shape).reshape(shape), z["c3_%s_fwd" % key]) < 1e-13
+        hs = shape[:2] + (shape[2] // 2 + 1,)
+        assert aerror(oracle_r2c(z["r3_%s_in" % key], shape).reshape(hs), z["r3_%s_out" % key]) < 1e-13
+        assert aerror(oracle_c2r(z["r3_%s_out" % key], shape).reshape(shape), z["r3_%s_in" % key] * np.prod(shape)) < 1e-13
+    for n in (16, 15, 1000, 243):
+        for kind in range(11):
+            got = oracle_r2r(z["k%d_n%d_in" % (kind, n)], (n,), [kind])
+            assert aerror(got, z["k%d_n%d_out" % (kind, n)]) < 1e-13, (kind, n)
+
+
+def test_oracle_generic_prime_path_against_the_direct_sum():
+    """the oracle's O(n^2) prime solver (fftw_oracle.c dft_generic, restating A.c:3390-3448: folded
+    x[j] +- x[n-j] Hartley-like sums) and the product's BflyOdd butterflies use the same symmetric
+    formula; this check is structurally different -- the plain defining sum, every term computed on
+    its own in long double with the angle reduced exactly -- for every odd prime the reference's generic
+    solver serves (p < 173, A.h:1108-1114) and the next few beyond it"""
+    from golden.make_golden import dft_ld
+    rng2 = np.random.default_rng(173)
+    primes = [p for p in range(3, 200) if all(p % q for q in range(2, int(p ** 0.5) + 1))]
+    assert 167 in primes and 173 in primes
+    for p in primes:
+        x = (rng2.random(p) - 0.5) + 1j * (rng2.random(p) - 0.5)
+        for sign in (-1, 1):
+            want = dft_ld(x, sign).astype(np.complex128)
+            assert aerror(oracle_dft(x, (p,), 1, sign), want) < 1e-14, p

@@ -489,6 +489,32 @@ def test_gpu_r2r_r2hc_equals_r2c_large():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [243, 1 << 16])
+def test_gpu_r2r_r2hc_equals_r2c_bitwise_when_the_kernels_are_the_same(monkeypatch, n):
+    """Where R2HC and r2c run the SAME kernels -- the unfused plans (FFTW_AMD_R2R_UNFUSED=1: r2c steps, then a
+    separate r2r step that only reorders), and odd lengths, which are never fused -- the halfcomplex output
+    is the r2c half spectrum bit for bit.  (The fused large-n plans end in different kernels -- the radix-4
+    untangle with the R2HC store hook against the streaming untangle -- whose FMA contractions differ: they
+    are compared to rounding in test_gpu_r2r_r2hc_equals_r2c_large.)"""
+    import torch
+    monkeypatch.setenv("FFTW_AMD_R2R_UNFUSED", "1")
+    hm = 5
+    x = torch.rand(hm * n, dtype=torch.float64, device="cuda") - 0.5
+    hc = torch.zeros_like(x)
+    spec = torch.zeros(hm * (n // 2 + 1), dtype=torch.complex128, device="cuda")
+    p = fa.plan_many_r2r(1, [n], hm, x, None, 1, n, hc, None, 1, n, [fa.R2HC])
+    q = fa.plan_many_dft_r2c(1, [n], hm, x, None, 1, n, spec, None, 1, n // 2 + 1)
+    p.execute()
+    q.execute()
+    q.sync()
+    p.sync()
+    hc = hc.view(hm, n)
+    spec = spec.view(hm, n // 2 + 1)
+    assert torch.equal(hc[:, :n // 2 + 1], spec.real.contiguous())
+    assert torch.equal(hc[:, n // 2 + 1:], torch.flip(spec.imag[:, 1:(n + 1) // 2], dims=[1]).contiguous())
+
+
+@pytest.mark.gpu
 def test_gpu_r2r_reference_verifier():
     import torch
     for kinds, shape in [([fa.REDFT10], (1000,)), ([fa.RODFT11, fa.REDFT00], (50, 60)),

@@ -41,6 +41,80 @@ def test_sharded_plan_is_built_without_a_device_and_uses_one_replica_per_shard()
             sp.execute()
 
 
+def test_gather_schedule_all_gather_for_equal_shards_broadcasts_for_ragged_tails():
+    """argument layout of the RCCL gather (fftw_amd_sharded_gather_ops: exactly the calls
+    fftw_amd_sharded_all_gather issues inside its group), checked without a device: equal shards -> one
+    ncclAllGather per rank with the shard's byte count; a ragged block-rule tail -> one ncclBroadcast per
+    non-empty shard and rank, root = the shard, receive pointer = that shard's place in the rank's image."""
+    n = 256
+    odist_bytes = n * 16
+
+    def plan(b, ndev):
+        cuts = [fa.shard_range(b, ndev, g) for g in range(ndev)]
+        ins = [np.zeros((max(1, hi - lo), n), dtype=complex) if hi > lo else None for lo, hi in cuts]
+        outs = [np.zeros_like(a) if a is not None else None for a in ins]
+        sp = fa.plan_many_dft_sharded(1, [n], b, list(range(ndev)), ins, None, 1, n, outs, None, 1, n, fa.FORWARD)
+        return sp, cuts, outs
+
+    # 8 transforms on 4 devices: equal shards of 2
+    sp, cuts, outs = plan(8, 4)
+    full = [0x10000000 * (d + 1) for d in range(4)]
+    ops = sp.gather_ops(full)
+    assert len(ops) == 4
+    for d, (kind, rank, root, send, recv, nbytes) in enumerate(ops):
+        assert (kind, rank, root) == (0, d, -1)
+        assert send == outs[d].ctypes.data and recv == full[d] and nbytes == 2 * odist_bytes
+    # 7 transforms on 4 devices: shards 2, 2, 2, 1 -> broadcasts
+    sp, cuts, outs = plan(7, 4)
+    ops = sp.gather_ops(full)
+    assert len(ops) == 16
+    k = 0
+    for g, (lo, hi) in enumerate(cuts):
+        for d in range(4):
+            kind, rank, root, send, recv, nbytes = ops[k]
+            k += 1
+            assert (kind, rank, root) == (1, d, g)
+            assert send == outs[g].ctypes.data and recv == full[d] + lo * odist_bytes and nbytes == (hi - lo) * odist_bytes
+    # 2 transforms on 3 devices: the empty trailing shard takes part in no call
+    sp, cuts, outs = plan(2, 3)
+    ops = sp.gather_ops(full[:3])
+    assert len(ops) == 6 and {o[2] for o in ops} == {0, 1} and all(o[5] == odist_bytes for o in ops)
+
+
+def test_rccl_entry_points_resolve():
+    """the loader of the gather (sharded.c rccl_load_once) opens librccl.so once per process and resolves the
+    seven entry points it calls; no RCCL call is made (works without a GPU)"""
+    if not any(os.path.exists(os.path.join(d, "librccl.so")) for d in ("/opt/rocm/lib", "/usr/lib", "/usr/local/lib")):
+        pytest.skip("no librccl.so on this machine")
+    assert fa.lib.fftw_amd_rccl_probe() == 7
+    assert fa.lib.fftw_amd_rccl_probe() == 7      # second call: same table, no second dlopen
+
+
+@pytest.mark.gpu
+def test_replicas_live_on_their_shards_device():
+    """every replica's tables and scratch are allocated on devs[g] (the planner runs with that device current:
+    mk_sharded), not on whatever device the calling thread had selected; the caller's device is restored.
+    With >= 2 visible devices the shards go to devices 0 and 1, otherwise both to device 0."""
+    import torch
+    ndevs = fa.device_count()
+    devs = [0, 1] if ndevs >= 2 else [0, 0]
+    n, b = 1 << 16, 6
+    ins = [torch.zeros(3, n, dtype=torch.complex128, device="cuda:%d" % d) for d in devs]
+    outs = [torch.zeros_like(t) for t in ins]
+    if ndevs >= 2:
+        fa.lib.fftw_amd_set_device(ndevs - 1)      # a current device that is neither shard's (or the last one)
+    before = fa.lib.fftw_amd_get_device()
+    sp = fa.plan_many_dft_sharded(1, [n], b, devs, ins, None, 1, n, outs, None, 1, n, fa.FORWARD)
+    assert fa.lib.fftw_amd_get_device() == before
+    assert [sp.replica_device(g) for g in range(2)] == devs
+    sp.execute()
+    sp.sync()
+    fa.lib.fftw_amd_set_device(0)
+    # a device that does not exist is refused at plan time
+    with pytest.raises(ValueError):
+        fa.plan_many_dft_sharded(1, [n], b, [0, ndevs + 3], ins, None, 1, n, outs, None, 1, n, fa.FORWARD)
+
+
 @pytest.mark.gpu
 def test_two_shards_on_one_device_match_the_oracle_and_gather():
     import torch
