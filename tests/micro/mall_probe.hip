@@ -168,6 +168,54 @@ __global__ void __launch_bounds__(256, 2) k_pair_g(const cplx *__restrict__ in, 
     }
 }
 
+// ---- H: transforms whose intermediate fits an XCD's L2 (n = 2^16: 1 MiB).  ONE launch; the workgroups of XCD x
+// (= blockIdx % 8) run pass 1 of their m-th transform followed by pass 2 of their (m - D)-th, the intermediate in a
+// per-XCD ring of R slots.  No waits (bandwidth only).  n = 256 x 256: pass-1 tile = 256 rows x 32 columns (512-B
+// segments at a 4 KiB pitch), pass-2 tile = 32 contiguous rows in, 256 x 32 transposed out.  LOG2N 15..18.
+template <int P_IN, int P_SS, int P_SL, int P_OUT>
+__global__ void __launch_bounds__(256, 2) k_xcd(const cplx *__restrict__ in, cplx *__restrict__ scr, cplx *__restrict__ out,
+                                                int per_xcd, int D, int R, int log2n, int remap) {
+    const unsigned b = blockIdx.x;
+    const unsigned x = remap ? (b & 7) : (b / (gridDim.x >> 3));
+    const unsigned j = remap ? (b >> 3) : (b % (gridDim.x >> 3));
+    const int tiles = 1 << (log2n - 13);                 // tiles of 8192 elements per pass
+    const int L2len = 256, L1len = 1 << (log2n - 8);     // n = L1len x 256; pass 1 = columns of the [L1len][256] view
+    // per-XCD order: m-th group = [A(m) tiles][B(m - D) tiles]
+    const unsigned per = 2u * tiles;
+    unsigned m = j / per, w = j % per;
+    int kind = w < (unsigned)tiles ? 1 : 2;
+    int i = kind == 1 ? w : w - tiles;
+    int mm = kind == 1 ? (int)m : (int)m - D;
+    if (mm < 0 || mm >= per_xcd) return;
+    const i64 n = (i64)1 << log2n;
+    const i64 t = (i64)x * per_xcd + mm;                  // transform id: XCD x owns a contiguous range
+    const cplx *S = scr + ((i64)x * R + (mm % R)) * n;
+    cplx *SW = scr + ((i64)x * R + (mm % R)) * n;
+    cplx v[32];
+    const int cols = 8192 / L1len;                        // columns per pass-1 tile (32 for 2^16)
+    if (kind == 1) {
+        // tile i: columns [i*cols, (i+1)*cols) of the [L1len][256] image; thread: c = tid % cols, r0 = tid / cols
+        const int c = threadIdx.x % cols, r0 = threadIdx.x / cols, rstep = 256 / cols;
+        const cplx *sp = in + t * n + (i64)i * cols + c + (i64)r0 * L2len;
+        cplx *dp = SW + (i64)i * cols + c + (i64)r0 * L2len;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = ld<P_IN>(sp + (i64)k * rstep * L2len);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) st<P_SS>(dp + (i64)k * rstep * L2len, v[k]);
+    } else {
+        // tile i: 32 contiguous rows of 256 -> transposed store: element (row r, col c) -> out[c * L1len + r]
+        const cplx *sp = S + (i64)i * 8192 + threadIdx.x;
+        const int r = threadIdx.x & 31, c0 = threadIdx.x >> 5;     // 32 adjacent rows fastest across lanes: 512-B segments
+        cplx *dp = out + t * n + (i64)i * 32 + r + (i64)c0 * L1len;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = ld<P_SL>(sp + k * 256);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) st<P_OUT>(dp + (i64)k * 8 * L1len, v[k]);
+    }
+}
+
 static hipEvent_t e0, e1;
 template <class F> static double bestms(F f, int reps = 3) {
     f(); CK(hipDeviceSynchronize());
@@ -408,6 +456,33 @@ int main(int argc, char **argv) {
             }
             printf("\n");
             fflush(stdout);
+        }
+    }
+    if (!*only || strchr(only, 'H')) {
+        printf("== H. intermediate in the XCD's L2: one launch, XCD x runs pass 1 of its m-th transform then pass 2 of its (m-D)-th; 4 GiB in, 4 GiB out; no arithmetic, no waits\n");
+        printf("   us per transform and TB/s on the ALGORITHMIC bytes (32 n per transform); 'two launches' = pass 1 over everything, then pass 2 (scratch = 4 GiB)\n");
+        printf("%6s %3s %3s %6s | %10s %8s | %10s %8s | %10s %8s\n", "log2n", "D", "R", "remap", "pppp us", "TB/s", "nppn us", "TB/s", "nnnn us", "TB/s");
+        for (int log2n = 15; log2n <= 18; ++log2n) {
+            const i64 n = (i64)1 << log2n;
+            const int NT = (int)((4096 * MiB) / (16 * n));      // transforms in 4 GiB
+            const int per_xcd = NT / 8, tiles = 1 << (log2n - 13);
+            const double alg = 32.0 * n * NT;
+            // two launches: D = per_xcd (all pass 1 first), ring = everything
+            struct { int D, R, remap; } V[] = { { 1, 2, 1 }, { 2, 3, 1 }, { 2, 4, 1 }, { 4, 6, 1 }, { 1, 2, 0 }, { per_xcd, per_xcd, 1 } };
+            for (unsigned k = 0; k < sizeof(V) / sizeof(V[0]); ++k) {
+                const int D = V[k].D, R = V[k].R;
+                if ((i64)8 * R * n * 16 > 2048 * MiB && D != per_xcd) continue;
+                cplx *scrp = D == per_xcd ? out : scr;          // the two-launch form needs a 4 GiB scratch: borrow the upper half of `out`
+                cplx *outp = out;
+                if (D == per_xcd) scrp = out + (i64)NT * n;     // out is 8 GiB: second half
+                const unsigned nb = 8u * (unsigned)(per_xcd + D) * 2u * tiles;
+                double t0 = bestms([&] { k_xcd<0, 0, 0, 0><<<nb, 256>>>(in, scrp, outp, per_xcd, D, R, log2n, V[k].remap); });
+                double t1 = bestms([&] { k_xcd<1, 0, 0, 1><<<nb, 256>>>(in, scrp, outp, per_xcd, D, R, log2n, V[k].remap); });
+                double t2 = bestms([&] { k_xcd<1, 1, 1, 1><<<nb, 256>>>(in, scrp, outp, per_xcd, D, R, log2n, V[k].remap); });
+                printf("%6d %3d %3d %6d | %10.3f %8.2f | %10.3f %8.2f | %10.3f %8.2f%s\n", log2n, D == per_xcd ? -1 : D, D == per_xcd ? -1 : R, V[k].remap,
+                       t0 * 1e3 / NT, alg / t0 / 1e9, t1 * 1e3 / NT, alg / t1 / 1e9, t2 * 1e3 / NT, alg / t2 / 1e9, D == per_xcd ? "   (all of pass 1, then all of pass 2)" : "");
+                fflush(stdout);
+            }
         }
     }
     return 0;

@@ -1095,15 +1095,17 @@ def test_planner_returns_null_when_the_device_is_out_of_memory(torch_dev):
     torch, dev = torch_dev
     torch.cuda.empty_cache()
     free0, _ = torch.cuda.mem_get_info()
-    hog = torch.empty(max(0, free0 - (96 << 20)), dtype=torch.uint8, device=dev)      # leave ~96 MiB
+    hog = torch.empty(max(0, free0 - (160 << 20)), dtype=torch.uint8, device=dev)     # leave ~160 MiB
+    fa.set_chunk_bytes(1 << 30)
     try:
-        n, b = 1 << 20, 64
+        n, b = 1 << 20, 256
         x = torch.zeros(8, dtype=torch.complex128, device=dev)      # the planner only needs addresses
         with pytest.raises(ValueError):
-            fa.plan_many_dft(1, [n], b, x, None, 1, n, x, None, 1, n, fa.FORWARD)      # needs 2 lanes x 128 MiB of scratch
+            fa.plan_many_dft(1, [n], b, x, None, 1, n, x, None, 1, n, fa.FORWARD)      # needs 2 lanes x 1 GiB of scratch
         free1, _ = torch.cuda.mem_get_info()
-        assert free1 > (64 << 20)                                   # the failed plan gave its tables back
+        assert free1 > (96 << 20)                                   # the failed plan gave its tables back
     finally:
+        fa.set_chunk_bytes(0)
         del hog
         torch.cuda.empty_cache()
     # and planning works again afterwards

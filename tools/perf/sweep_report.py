@@ -1,7 +1,7 @@
 """The north-star sweep on one GPU: powers of two 2^10 ... 2^24, 7-smooth and {11, 13}-containing lengths, the
 primes 17 / 1031 / 65537 (O(p^2) stage, Bluestein, Rader), some 2-D / 3-D shapes; batched c2c, forward, out of
 place, FFTW_ESTIMATE, about 4 GiB of input each.  GFLOPS = 5 N log2 N * howmany / t, whole % = 32 N howmany / t
-against 8 TB/s.  -> profiles/r02_sweep.txt"""
+against 8 TB/s.  -> profiles/r0x_sweep.txt (r03: with chunk lanes)"""
 import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
