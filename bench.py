@@ -342,7 +342,10 @@ def run_workload(name, batch_override, steps, warmup, torch, fa, dist, world, ra
             "per_launch": {
                 "kernel": kernel, "achieved": pl_achieved, "frac": pl_achieved / HBM_PEAK_GBS,
                 "avg_launch_ms": avg_ms, "launches_per_step": launches, "alg_bytes_per_launch": bytes_per_launch,
-                "note": "bytes the launch itself reads + writes (one pass over its chunk) / its HIP-event duration, launches serialised",
+                "concurrent_lanes": plan.lanes,
+                "note": "bytes the launch itself reads + writes (one pass over its chunk) / its HIP-event duration on its own "
+                        "stream; with chunk lanes > 1 that many launches share the chip at any time, so the chip-level rate "
+                        "is about lanes x this figure and the sum of steps_ms exceeds ms_per_step",
             },
             "steps_ms": [round(t[1], 4) for t in prof],
         }

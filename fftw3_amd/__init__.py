@@ -56,6 +56,7 @@ F_SWAP_IN, F_SWAP_OUT, F_REAL_IN, F_REAL_OUT = 1, 2, 4, 8
 F_MUL_TABLE, F_MUL_CONJ, F_PERM_SRC, F_PERM_DST, F_CONJ_OUT, F_TW_IN = 16, 32, 64, 128, 256, 512
 F_R2C_ROWS = 1024
 F_C2R_ROWS = 2048
+F_LO_DFT = 1 << 14
 
 
 class StepDesc(C.Structure):
@@ -181,6 +182,7 @@ _sig("fftw_amd_plan_sync", None, _vp)
 _sig("fftw_amd_plan_workspace_bytes", C.c_size_t, _vp)
 _sig("fftw_amd_set_chunk_bytes", None, C.c_size_t)
 _sig("fftw_amd_plan_paired", C.c_int, _vp)
+_sig("fftw_amd_plan_lanes", C.c_int, _vp)
 _sig("fftw_amd_set_device", C.c_int, C.c_int)
 _sig("fftw_amd_get_device", C.c_int)
 _sig("fftw_amd_plan_num_steps", C.c_int, _vp)
@@ -315,6 +317,11 @@ class Plan(object):
     @property
     def paired(self):
         return bool(lib.fftw_amd_plan_paired(self.handle))
+
+    @property
+    def lanes(self):
+        """chunk lanes of the plan: chunk c runs on stream c % lanes (1: serial chunks); known after the first execution"""
+        return lib.fftw_amd_plan_lanes(self.handle)
 
     @property
     def workspace_bytes(self):

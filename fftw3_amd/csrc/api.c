@@ -919,6 +919,7 @@ int fftw_amd_plan_get_step(const fftw_plan p, int i, fftw_amd_step_desc *out) {
 }
 long long fftw_amd_plan_chunk(const fftw_plan p) { return p->chunk; }
 int fftw_amd_plan_paired(const fftw_plan p) { return p ? p->pair : 0; }
+int fftw_amd_plan_lanes(const fftw_plan p) { return (p && p->lanes > 1) ? p->lanes : 1; }
 long long fftw_amd_plan_batch(const fftw_plan p) { return p->batch; }
 
 /* returns the length in doubles (int64 tables are reported as doubles holding

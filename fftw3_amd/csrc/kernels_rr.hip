@@ -99,12 +99,16 @@ static void launch_3s(const P3SArgs &pa, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((pass3s_kernel<R1>), grid, dim3(256), lds, st, pa);
 }
 
+/* FFTW_AMD_F_LO_DFT steps (rows + a DFT across the rows of a tile): kernels_sq.hip */
+int fa_launch_lo_dft(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables, i64 cs, i64 cn, hipStream_t st);
+
 /* contiguous rows of 2048 / 4096 / 8192 / 16384 in one pass; 1 = not applicable */
 int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                      i64 cs, i64 cn, hipStream_t st) {
     P3SArgs pa;
     int bd = d->batch_dim, T;
     i64 sbase = d->src_base, dbase = d->dst_base;
+    if (d->flags & FFTW_AMD_F_LO_DFT) return fa_launch_lo_dft(d, bufs, tables, cs, cn, st);
     if ((d->L != 2048 && d->L != 4096 && d->L != 8192 && d->L != 16384) || d->src_im != 1 || d->dst_im != 1 || d->tw_n ||
         d->is_l != 2 || d->os_l != 2 || d->tile_lo_n > 1 ||
         (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))

@@ -44,6 +44,8 @@ struct P3SArgs {
     const cplx *tw_lo;
     const cplx *tw_hi;
     int tw_shift;
+    /* FFTW_AMD_F_LO_DFT steps (XROW forms, pass3q.hpp): distance between the rows of a tile, in doubles */
+    i64 srs, drs;
 };
 
 /* MODE 0: complex rows.
@@ -56,8 +58,12 @@ struct P3SArgs {
            (E' = Y[l] + conj Y[L-l], O' = (Y[l] - conj Y[L-l]) w_n^-l; both read from global memory, the second run
            backwards) with real and imaginary part swapped, and stage C stores (Im, Re): the unnormalised backward
            DFT by the swap identity.
-   Reference: ct_hc2c + hc2cfdft / hc2cbdft, fftw/fftw_api.c:5661-5845; r2crows.hpp is the two-stage form. */
-template <int R1, int MODE = 0>
+   Reference: ct_hc2c + hc2cfdft / hc2cbdft, fftw/fftw_api.c:5661-5845; r2crows.hpp is the two-stage form.
+   XROW (MODE 0, T = 2 or 4; FFTW_AMD_F_LO_DFT steps): the T rows of a tile are the inner tile component -- srs / drs
+   apart, the tile index runs over dims[0] -- and a DFT of length T across them (no twiddle) is taken in the same
+   registers: every tile is transformed as a 2-D array T x L.  The last trip of a two-dimensional transform whose
+   strided axis is T x L0 (planner.c emit_rows_lo_dft; pass3q.hpp is the 512-item form for four rows of 4096). */
+template <int R1, int MODE = 0, bool XROW = false>
 __global__ void __launch_bounds__(256, 2)
 pass3s_kernel(const P3SArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
@@ -67,18 +73,19 @@ pass3s_kernel(const P3SArgs a) {
 
     i64 tile, soff, doff, twb_unused;
     fa_block_offsets<false>(a, tile, soff, doff, twb_unused);
-    const i64 t0 = tile * T;
-    const int Tcur = (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
+    const i64 t0 = XROW ? tile : tile * T;
+    const int Tcur = XROW ? T : (int)((a.dn[0] - t0 < T) ? (a.dn[0] - t0) : T);
     const double *src = a.src + soff + t0 * a.dis[0];
     double *dst = a.dst + doff + t0 * a.dos[0];
+    const i64 rs_in = XROW ? a.srs : a.dis[0], rs_out = XROW ? a.drs : a.dos[0];   /* row to row inside the tile */
 
     /* ---- stage A: item a = tid, one radix-R1 butterfly per row */
     cplx x[T][R1];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const double *p = src + (i64)t * a.dis[0] + 2 * tid;
+        const double *p = src + (i64)t * rs_in + 2 * tid;
         if (MODE == 2 && t < Tcur) {
-            const double *row = src + (i64)t * a.dis[0];
+            const double *row = src + (i64)t * rs_in;
             const cplx wb = tw2(a.tw_lo, a.tw_hi, a.tw_shift, tid);
 #pragma unroll
             for (int i = 0; i < R1; ++i) {
@@ -103,6 +110,19 @@ pass3s_kernel(const P3SArgs a) {
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int i = 0; i < R1; ++i) { double s = x[t][i].x; x[t][i].x = x[t][i].y; x[t][i].y = s; }
+    }
+    if constexpr (XROW) {
+        /* DFT-T across the rows of the tile, element by element */
+        static_assert(!XROW || T == 2 || T == 4, "cross-row butterfly: two or four rows per tile");
+#pragma unroll
+        for (int i = 0; i < R1; ++i) {
+            cplx c[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) c[t] = x[t][i];
+            Bfly<T>::run(c);
+#pragma unroll
+            for (int t = 0; t < T; ++t) x[t][i] = c[t];
+        }
     }
     {
         cplx pw[RB<R1>::bits];
@@ -230,7 +250,7 @@ pass3s_kernel(const P3SArgs a) {
         for (int v = 0; v < 2; ++v) {
             const int kb = cd1[v] + R1 * cd2[v];
             const cplx wb = tw2(a.tw_lo, a.tw_hi, a.tw_shift, kb);
-            double *row = dst + (i64)ct[v] * a.dos[0];
+            double *row = dst + (i64)ct[v] * rs_out;
             if (ct[v] < Tcur) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
@@ -255,14 +275,14 @@ pass3s_kernel(const P3SArgs a) {
         RB<16>::run(z[v]);
         if (MODE == 2) {
             if (ct[v] < Tcur) {
-                double *p = dst + (i64)ct[v] * a.dos[0] + 2 * (cd1[v] + R1 * cd2[v]);
+                double *p = dst + (i64)ct[v] * rs_out + 2 * (cd1[v] + R1 * cd2[v]);
 #pragma unroll
                 for (int c = 0; c < 16; ++c) *reinterpret_cast<cplx *>(p + (i64)c * (32 * R1)) = c_make(z[v][c].y, z[v][c].x);
             }
             continue;
         }
         if (ct[v] < Tcur) {
-            double *p = dst + (i64)ct[v] * a.dos[0] + 2 * (cd1[v] + R1 * cd2[v]);
+            double *p = dst + (i64)ct[v] * rs_out + 2 * (cd1[v] + R1 * cd2[v]);
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 cplx w = z[v][c];

@@ -1171,6 +1171,69 @@ static int collect_loops(const plan *p, const fa_dim *dims, int rank, int axis,
     return 0;
 }
 
+
+/* A two-dimensional transform n0 x n1 whose rows (n1 = 2048 or 4096 points, contiguous) have a one-trip rows
+   kernel holding T whole rows per tile, and whose strided axis is n0 = T x L0 with 1024 < n0 <= 4096 and L0 <= 1024
+   a register-kernel length, in TWO full-rate trips (pass3q.hpp, pass3s.hpp XROW): the strided axis is split
+   Cooley-Tukey over the row index r = s + T r' --
+     trip 1  the ordinary strided L0-point pass of every row class s (128-byte segments), twiddle w_n0^(s k') on
+             the output, stored as [k'][s][c]: the T rows that belong together are adjacent
+     trip 2  tiles k' of T rows: the row transforms and the DFT of length T across the rows in the same registers,
+             X[k' + L0 q] = sum_s w_T^(s q) DFT_n1(Y_s[k'])
+   Round 2 ran 4096 x 4096 as rows + 64 x 64 columns (three trips, 23 %) and strided axes of 1025 ... 2048 points on
+   the narrow-tile kernel (64-byte segments, 3.2 TB/s).  The last step has no other executor, so everything it
+   needs is settled here: interleaved unit-stride rows, 16-byte aligned arrays, even strides, at most one batch
+   loop, no FFTW_UNALIGNED.  1 = emitted. */
+static int has_register_kernel(i64 L);
+static int emit_rows_lo_dft(plan *p, fa_loc in, fa_loc out, int sw_in, int sw_out) {
+    const fa_dim *col = &p->dims[0], *row = &p->dims[1];
+    sdim d[3];
+    int nd, sbuf;
+    i64 N1, N0, T = 0, L0, img, chunk = p->hrank ? p->chunk : 1;
+    fftw_amd_step_desc *st;
+    if (p->rank != 2 || p->hrank > 1 || getenv("FFTW_AMD_NO_TUNED") || getenv("FFTW_AMD_NO_LO_DFT")) return 0;
+    N1 = row->n; N0 = col->n;
+    if ((N1 != 2048 && N1 != 4096) || N0 <= 1024 || N0 > 4096) return 0;
+    if (N1 == 4096 && N0 <= 2048 && N0 % 2 == 0 && has_register_kernel(N0 / 2)) T = 2;      /* pass3s<16>, XROW */
+    else if (N0 % 4 == 0 && has_register_kernel(N0 / 4)) T = 4;                             /* pass3q / pass3s<8>, XROW */
+    if (!T) return 0;
+    L0 = N0 / T;
+    if (row->is != 2 || row->os != 2 || in.im != 1 || out.im != 1) return 0;
+    if (col->is < 2 * N1 || col->os < 2 * N1 || (col->is % 2) || (col->os % 2)) return 0;
+    if (p->flags & FFTW_UNALIGNED) return 0;
+    if (((size_t)p->ri % 16) || ((size_t)p->ro % 16)) return 0;
+    if (p->hrank && ((p->hdims[0].is % 2) || (p->hdims[0].os % 2))) return 0;
+    if (fa_hip_r3_tile((int)N1) <= 0) return 0;
+    img = N0 * N1 * 2;
+    sbuf = buf_acquire(p, chunk * img);
+    {
+        /* trip 1: L0-point column pass of every row class s, twiddle w_n0^(s k') on the output */
+        fa_loc scr = { sbuf, 0, 1 };
+        d[0].n = N1; d[0].is = 2;       d[0].os = 2;      d[0].tw = 0; d[0].is_batch = 0;    /* columns c */
+        d[1].n = T;  d[1].is = col->is; d[1].os = 2 * N1; d[1].tw = 1; d[1].is_batch = 0;    /* row class s */
+        nd = 2;
+        if (p->hrank) { d[2].n = chunk; d[2].is = p->hdims[0].is; d[2].os = img; d[2].tw = 0; d[2].is_batch = 1; nd = 3; }
+        emit_pass(p, in, scr, L0, T * col->is, T * 2 * N1, d, nd, N0, sw_in);
+        if (p->failed) return 1;
+        /* trip 2: tiles k' of T rows: DFT-n1 along every row and DFT-T across them */
+        d[0].n = L0; d[0].is = T * 2 * N1; d[0].os = col->os; d[0].tw = 0; d[0].is_batch = 0;
+        nd = 1;
+        if (p->hrank) { d[1].n = chunk; d[1].is = img; d[1].os = p->hdims[0].os; d[1].tw = 0; d[1].is_batch = 1; nd = 2; }
+        emit_pass(p, scr, out, N1, 2, 2, d, nd, 0, sw_out);
+        if (p->failed) return 1;
+        st = &p->steps[p->nsteps - 1];
+        st->tile_lo_n = (int)T;
+        st->tile_lo_is = 2 * N1;
+        st->tile_lo_os = L0 * col->os;
+        st->flags |= FFTW_AMD_F_LO_DFT;
+        st->variant = FFTW_AMD_K_R3;
+        st->tile = (int)T;
+        p->est_flops += 5.0 * (double)(N0 * N1) * (double)chunk * (T == 4 ? 2.0 : 1.0);     /* the radix-T stage */
+    }
+    buf_release(p, sbuf);
+    return 1;
+}
+
 static void build_c2c(plan *p) {
     int a, first = 1;
     int sw_in = (p->sign > 0) ? FFTW_AMD_F_SWAP_IN : 0;
@@ -1187,6 +1250,7 @@ static void build_c2c(plan *p) {
         emit_pass(p, in, out, 1, 0, 0, d, nd, 0, 0);
         return;
     }
+    if (emit_rows_lo_dft(p, in, out, sw_in, sw_out)) return;
     for (a = p->rank - 1; a >= 0; --a) {
         fa_axis ax;
         memset(&ax, 0, sizeof(ax));
@@ -2188,9 +2252,10 @@ int fa_device_init(plan *p) {
         !p->single_chunk && (p->batch + p->chunk - 1) / p->chunk >= 2) {
         i64 nch = (p->batch + p->chunk - 1) / p->chunk, per = 0;
         for (i = 2; i < p->nbufs; ++i) per += p->buf_reals[i];
-        /* a chunk whose scratch is beyond the budget anyway (one transform of hundreds of MB: nothing stays in
-           the Infinity Cache whatever the order) gains nothing from a second lane and loses a little to the
-           doubled footprint (cfg4, n = 15 375 360: 68.5 ms serial, 69 ... 75 ms with two lanes) */
+        /* a chunk whose scratch is beyond the budget anyway (one transform with hundreds of MB of scratch: two of
+           them in flight leave nothing on the die) gains nothing from a second lane and loses to the doubled
+           footprint -- cfg4, n = 15 375 360, 246 MB of scratch per transform: 67.0 ms serial, 71 ... 76 ms with two
+           lanes; one 4096 x 4096 image (256 MiB): 14.7 serial, 14.5 with two (tools/perf/perf_lanes_gate.sh) */
         if ((size_t)per * sizeof(double) > p->cfg.chunk_bytes) nch = 0;
         p->lanes = p->cfg.lanes > FA_MAXLANES ? FA_MAXLANES : p->cfg.lanes;
         if (p->lanes > nch) p->lanes = nch > 0 ? (int)nch : 1;
@@ -2446,9 +2511,9 @@ static void fa_run_locked(plan *p, double *ri, double *ii, double *ro, double *i
         i64 nchunks = (p->batch + p->chunk - 1) / p->chunk, ev = 0, c = 0;
         void **events = NULL;
         const int pipe = p->nslots > 1 && p->pstream[0] && p->lanes <= 1;
-        /* profiled executions run the lanes one after the other on the caller's stream (slot 0), so that the
-           HIP events around a launch time that launch alone */
-        const int lanes = (p->lanes > 1 && !p->prof_ms) ? p->lanes : 1;
+        /* profiled executions keep the lanes: the HIP events around a launch sit on the lane's own stream and time
+           the launch as it really runs, beside the other lane's (rocprofv3's kernel durations see the same) */
+        const int lanes = p->lanes > 1 ? p->lanes : 1;
         if (p->prof_ms) events = (void **)malloc(sizeof(void *) * (size_t)(2 * nchunks * p->nsteps));
         if (pipe || lanes > 1) {
             /* the side streams start after everything already queued on the caller's stream */
@@ -2596,7 +2661,7 @@ char *fa_sprint(const plan *p) {
             else if (d->variant == FFTW_AMD_K_C2R) sapp(s, cap, &len, d->aux_valid ? (d->aux_buf > 0 ? "c2r-rows+r2r-pre+post" : "c2r-rows+r2r-pre") : "c2r-rows");
             else if (d->variant == FFTW_AMD_K_P1024) sapp(s, cap, &len, "reg32x32");
             else if (d->variant == FFTW_AMD_K_RR) sapp(s, cap, &len, "reg2");
-            else if (d->variant == FFTW_AMD_K_R3) sapp(s, cap, &len, "reg3");
+            else if (d->variant == FFTW_AMD_K_R3) sapp(s, cap, &len, (d->flags & FFTW_AMD_F_LO_DFT) ? (d->tile_lo_n == 4 ? "reg3+dft4-across-rows" : "reg3+dft2-across-rows") : "reg3");
             else if (d->variant == FFTW_AMD_K_R1) sapp(s, cap, &len, "reg1");
             else if (d->variant == FFTW_AMD_K_BLUE) sapp(s, cap, &len, "bluestein-rows n=%lld", (long long)d->aux_n);
             else {

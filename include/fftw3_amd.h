@@ -216,7 +216,10 @@ enum {
     FFTW_AMD_F_C2R_ROWS  = 1 << 11,/* the transpose: reads L + 1 spectrum entries per row, c2r tangle, backward
                                       length-L pass, stores the real pairs (dst_im = 1) */
     FFTW_AMD_F_NT_IN     = 1 << 12,/* the source is read once per execution: nontemporal loads */
-    FFTW_AMD_F_NT_OUT    = 1 << 13 /* the destination is not read again by this plan: nontemporal stores */
+    FFTW_AMD_F_NT_OUT    = 1 << 13,/* the destination is not read again by this plan: nontemporal stores */
+    FFTW_AMD_F_LO_DFT    = 1 << 14 /* pass: the inner tile component is transformed too -- a DFT of length tile_lo_n across the
+                                      tile's tile_lo_n sequences (no twiddle), i.e. the step is the 2-D DFT tile_lo_n x L of every
+                                      tile (pass3q.hpp: four rows of 4096 points, the last trip of a 4096 x 4096 transform) */
 };
 
 int fftw_amd_plan_num_steps(const fftw_plan p);
@@ -228,6 +231,13 @@ long long fftw_amd_plan_batch(const fftw_plan p);
    c-1 followed by pass 1 of chunk c); fftw_amd_execute_profiled then reports every launch under step 0.
    Known once the plan has been set up on a device. */
 int fftw_amd_plan_paired(const fftw_plan p);
+/* Chunk lanes of a multi-pass plan (round 3): chunk c of the batch runs ALL its steps, in order, on stream
+   c % lanes in scratch slot c % lanes; the lanes share the chip, so the tail of one lane's launch is filled by
+   the other lane's next one and a chunk's scratch is re-read while it is still in the Infinity Cache
+   (default 2 lanes x 128 MiB of scratch; FFTW_AMD_LANES=1 restores serial chunks, and with them the pair
+   launches above).  The lanes fork from and join the plan's stream (fftw_amd_plan_set_stream) inside every
+   fftw_execute*.  1 for single-chunk, one-step and oversized-chunk plans.  Known once the plan is set up. */
+int fftw_amd_plan_lanes(const fftw_plan p);
 /* host copy of table `id` as interleaved doubles; returns its length in
    doubles (writes at most cap doubles). */
 long long fftw_amd_plan_table(const fftw_plan p, int id, double *dst, long long cap);

@@ -204,6 +204,10 @@ class Interp(object):
                 assert m.max() < s.tw_n
                 x = x * np.conj(self.tw2(s, m))
             y = np.fft.fft(x, axis=0)
+            if s.flags & fa.F_LO_DFT:
+                # the tile's inner component (appended last by _dims) is transformed too: 2-D DFT tile_lo_n x L
+                assert s.tile_lo_n > 1 and not s.tw_n
+                y = np.fft.fft(y, axis=-1)
             if s.tw_n and not (s.flags & fa.F_TW_IN):
                 m = l * twb
                 assert m.max() < s.tw_n

@@ -545,6 +545,79 @@ def test_reference_verifier_on_gpu(torch_dev, shape, vecn):
         assert e < TOL
 
 
+def test_square_4096_in_two_trips(torch_dev, monkeypatch):
+    """cfg5 unit (round 3): 4096 x 4096 as TWO trips -- the strided 1024-point pass over the four row classes,
+    then four rows per workgroup with the radix-4 butterfly across them (pass3q.hpp, FFTW_AMD_F_LO_DFT) --
+    against the oracle and against the three-trip plan (FFTW_AMD_NO_LO_DFT): both signs, a batch that runs in
+    several chunks on two lanes, in place, padded row pitch on both sides, new-array execute."""
+    torch, dev = torch_dev
+    n = 4096
+    rng = np.random.default_rng(4096)
+    x = crand(rng, 3, n * n)
+    xd = torch.from_numpy(x).to(dev)
+    want = {}
+    for sign in (-1, 1):
+        yd = torch.zeros_like(xd)
+        p = fa.plan_many_dft(2, [n, n], 3, xd, None, 1, n * n, yd, None, 1, n * n, sign)
+        assert len(p.steps()) == 2 and "dft4-across-rows" in p.sprint(), p.sprint()
+        p.execute()
+        torch.cuda.synchronize()
+        got = yd.cpu().numpy()
+        want[sign] = oracle_dft(x[:1], (n, n), 1, sign).reshape(1, n * n)
+        assert aerror(got[:1], want[sign]) < TOL
+        # the other images against the three-trip plan of round 2
+        monkeypatch.setenv("FFTW_AMD_NO_LO_DFT", "1")
+        zd = torch.zeros_like(xd)
+        q = fa.plan_many_dft(2, [n, n], 3, xd, None, 1, n * n, zd, None, 1, n * n, sign)
+        assert len(q.steps()) == 3, q.sprint()
+        q.execute()
+        torch.cuda.synchronize()
+        monkeypatch.delenv("FFTW_AMD_NO_LO_DFT")
+        assert aerror(got, zd.cpu().numpy()) < TOL
+        del zd, yd
+    # in place + new-array execute on another buffer
+    wd = xd[:1].clone()
+    r = fa.plan_many_dft(2, [n, n], 1, wd, None, 1, n * n, wd, None, 1, n * n, fa.FORWARD)
+    assert len(r.steps()) == 2
+    r.execute()
+    torch.cuda.synchronize()
+    assert aerror(wd.cpu().numpy(), want[-1]) < TOL
+    w2 = xd[:1].clone()
+    r.execute_dft(w2, w2)
+    torch.cuda.synchronize()
+    assert aerror(w2.cpu().numpy(), want[-1]) < TOL
+    del wd, w2
+    # rows padded to 4100 on the input side and 4104 on the output side (inembed / onembed)
+    xp = torch.zeros(n, n + 4, dtype=torch.complex128, device=dev)
+    xp[:, :n] = xd[0].view(n, n)
+    yp = torch.zeros(n, n + 8, dtype=torch.complex128, device=dev)
+    e = fa.plan_many_dft(2, [n, n], 1, xp, [n, n + 4], 1, n * (n + 4), yp, [n, n + 8], 1, n * (n + 8), fa.FORWARD)
+    assert len(e.steps()) == 2, e.sprint()
+    e.execute()
+    torch.cuda.synchronize()
+    assert aerror(yp[:, :n].contiguous().cpu().numpy().reshape(1, n * n), want[-1]) < TOL
+    assert float(yp[:, n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n0,n1,t", [(2048, 2048, 4), (2048, 4096, 2), (4096, 2048, 4), (1536, 2048, 4), (1280, 4096, 2),
+                                     (3072, 4096, 4)])
+def test_rows_with_a_dft_across_the_rows_of_a_tile(torch_dev, n0, n1, t):
+    """two-dimensional transforms whose strided axis is n0 = T x L0 (1024 < n0 <= 4096) over rows of 2048 / 4096
+    points: strided L0-point pass with the twiddle w_n0^(s k'), then tiles of T rows with the DFT-T across them
+    (pass3s_kernel XROW forms, pass3q.hpp; planner emit_rows_lo_dft).  Both signs, batch of 3, against the oracle."""
+    torch, dev = torch_dev
+    rng = np.random.default_rng(n0 + n1)
+    x = crand(rng, 3, n0 * n1)
+    xd = torch.from_numpy(x).to(dev)
+    for sign in (-1, 1):
+        yd = torch.zeros_like(xd)
+        p = fa.plan_many_dft(2, [n0, n1], 3, xd, None, 1, n0 * n1, yd, None, 1, n0 * n1, sign)
+        assert len(p.steps()) == 2 and ("dft%d-across-rows" % t) in p.sprint(), p.sprint()
+        p.execute()
+        torch.cuda.synchronize()
+        assert aerror(yd.cpu().numpy(), oracle_dft(x, (n0, n1), 3, sign).reshape(3, n0 * n1)) < TOL
+
+
 def test_mixed_radix_baseline_size_against_oracle(torch_dev):
     """cfg4 unit: N = 3*5*7*11*13*2^10, one transform against the oracle"""
     n = 3 * 5 * 7 * 11 * 13 * 1024

@@ -476,10 +476,16 @@ def test_streaming_access_flags_only_on_the_callers_side_and_only_for_large_batc
     assert st[0].src_buf == 0 and (st[0].flags & NT_IN) and not (st[0].flags & NT_OUT)         # writes scratch
     assert st[-1].dst_buf == 1 and (st[-1].flags & NT_OUT) and not (st[-1].flags & NT_IN)      # reads scratch
     # 2-D: the first axis writes the output array that the second axis reads back: no NT_OUT there
-    p2 = fa.plan_many_dft(2, [4096, 4096], 8, x, None, 1, 1 << 24, x.copy(), None, 1, 1 << 24, fa.FORWARD)
+    p2 = fa.plan_many_dft(2, [1024, 2048], 64, x, None, 1, 1 << 21, x.copy(), None, 1, 1 << 21, fa.FORWARD)
     s2 = p2.steps()
     assert s2[0].dst_buf == 1 and not (s2[0].flags & NT_OUT)
     assert s2[-1].dst_buf == 1 and (s2[-1].flags & NT_OUT)
+    # 4096 x 4096 (round 3: two trips through scratch): NT_IN on the strided pass, NT_OUT on the four-row pass only
+    p4 = fa.plan_many_dft(2, [4096, 4096], 8, x, None, 1, 1 << 24, x.copy(), None, 1, 1 << 24, fa.FORWARD)
+    s4 = p4.steps()
+    assert len(s4) == 2 and s4[0].src_buf == 0 and s4[0].dst_buf >= 2 and (s4[0].flags & NT_IN) and not (s4[0].flags & NT_OUT)
+    assert s4[1].src_buf >= 2 and s4[1].dst_buf == 1 and (s4[1].flags & NT_OUT) and not (s4[1].flags & NT_IN)
+    assert (s4[1].flags & fa.F_LO_DFT) and s4[1].tile_lo_n == 4
 
 
 def test_one_trip_rows_plans():
