@@ -37,8 +37,9 @@ def main():
     root, out = sys.argv[1], sys.argv[2]
     res = {}
     for w in ("c2c", "r2c", "mixed", "2d"):
-        f = glob.glob(os.path.join(root, "FETCH_SIZE_" + w, "**", "*counter_collection.csv"), recursive=True)
-        g = glob.glob(os.path.join(root, "WRITE_SIZE_" + w, "**", "*counter_collection.csv"), recursive=True)
+        # newest first: gpurun merges the files of a later run beside those of an earlier one
+        f = sorted(glob.glob(os.path.join(root, "FETCH_SIZE_" + w, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+        g = sorted(glob.glob(os.path.join(root, "WRITE_SIZE_" + w, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
         bj = os.path.join(root, "pmc_FETCH_SIZE_%s.json" % w)
         if not f or not g or not os.path.exists(bj):
             continue
