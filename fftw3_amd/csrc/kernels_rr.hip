@@ -142,14 +142,21 @@ int fa_launch_pass3s(const fftw_amd_step_desc *d, double *const *bufs, void *con
     else if (d->L == 4096) launch_3s<16>(pa, grid, st);
     else if (d->L == 8192) launch_3s<32>(pa, grid, st);
     else {
-        /* 16384: one workgroup of 512 items per row (pass3w.hpp) */
+        /* 16384: one workgroup of 512 items per row (pass3w.hpp); the store flags are template parameters */
         static std::atomic<unsigned> attr_done{0};
         const size_t lds = P3WGeom::lds_doubles * sizeof(double);
         if (fa_attr_needed(attr_done)) {
-            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel<0, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel<0, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FA_CHECK(hipFuncSetAttribute((const void *)pass3w_kernel<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             fa_attr_set(attr_done);
         }
-        hipLaunchKernelGGL(pass3w_kernel<0>, grid, dim3(512), lds, st, pa);
+        const bool sw = (d->flags & FFTW_AMD_F_SWAP_OUT) != 0, nt = (d->flags & FFTW_AMD_F_NT_OUT) != 0;
+        if (sw && nt) hipLaunchKernelGGL((pass3w_kernel<0, true, true>), grid, dim3(512), lds, st, pa);
+        else if (sw) hipLaunchKernelGGL((pass3w_kernel<0, true, false>), grid, dim3(512), lds, st, pa);
+        else if (nt) hipLaunchKernelGGL((pass3w_kernel<0, false, true>), grid, dim3(512), lds, st, pa);
+        else hipLaunchKernelGGL((pass3w_kernel<0, false, false>), grid, dim3(512), lds, st, pa);
     }
     return 0;
 }

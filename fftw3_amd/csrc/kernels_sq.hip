@@ -61,9 +61,23 @@ int fa_launch_lo_dft(const fftw_amd_step_desc *d, double *const *bufs, void *con
     pa.ntiles = pa.dn[0];
     pa.srs = d->tile_lo_is;
     pa.drs = d->tile_lo_os;
-    static std::atomic<unsigned> a0{0}, a1{0}, a2{0};
-    if (d->L == 2048) launch_sq(pass3s_kernel<8, 0, true>, a0, P3SGeom<8>::lds_doubles * sizeof(double), (unsigned)nblocks, 256, st, pa);
-    else if (T == 2) launch_sq(pass3s_kernel<16, 0, true>, a1, P3SGeom<16>::lds_doubles * sizeof(double), (unsigned)nblocks, 256, st, pa);
-    else launch_sq(pass3q_kernel, a2, P3QGeom::lds_doubles * sizeof(double), (unsigned)nblocks, 512, st, pa);
+    const int outf = ((d->flags & FFTW_AMD_F_SWAP_OUT) ? 1 : 0) | ((d->flags & FFTW_AMD_F_NT_OUT) ? 2 : 0);
+    static std::atomic<unsigned> a8[4], a16[4];
+    const size_t l8 = P3SGeom<8>::lds_doubles * sizeof(double), l16 = P3SGeom<16>::lds_doubles * sizeof(double);
+#define FA_SQ_CASE(F) case F: if (d->L == 2048) launch_sq(pass3s_kernel<8, 0, true, F>, a8[F], l8, (unsigned)nblocks, 256, st, pa); \
+                              else launch_sq(pass3s_kernel<16, 0, true, F>, a16[F], l16, (unsigned)nblocks, 256, st, pa); break;
+    if (d->L == 2048 || T == 2) {
+        switch (outf) { FA_SQ_CASE(0) FA_SQ_CASE(1) FA_SQ_CASE(2) FA_SQ_CASE(3) }
+    }
+#undef FA_SQ_CASE
+    else {
+        static std::atomic<unsigned> q00{0}, q01{0}, q10{0}, q11{0};
+        const size_t lq = P3QGeom::lds_doubles * sizeof(double);
+        const bool sw = (d->flags & FFTW_AMD_F_SWAP_OUT) != 0, nt = (d->flags & FFTW_AMD_F_NT_OUT) != 0;
+        if (sw && nt) launch_sq(pass3q_kernel<true, true>, q11, lq, (unsigned)nblocks, 512, st, pa);
+        else if (sw) launch_sq(pass3q_kernel<true, false>, q10, lq, (unsigned)nblocks, 512, st, pa);
+        else if (nt) launch_sq(pass3q_kernel<false, true>, q01, lq, (unsigned)nblocks, 512, st, pa);
+        else launch_sq(pass3q_kernel<false, false>, q00, lq, (unsigned)nblocks, 512, st, pa);
+    }
     return 0;
 }

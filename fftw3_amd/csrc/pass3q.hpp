@@ -44,6 +44,10 @@ struct P3QGeom {
 
 /* arguments: P3SArgs (pass3s.hpp) -- dims[0] = the tile loop (k'), srs / drs = distance between the four rows of a
    tile on the source / destination side */
+/* SW_OUT / NT_OUT (FFTW_AMD_F_SWAP_OUT / NT_OUT of the step) are compile-time: as run-time branches around the 32
+   stores they cost 27 spilled VGPRs in the last butterfly -- 108 bytes per lane of scratch traffic, +20 % bytes
+   leaving the XCDs per launch (rocprofv3 --pmc: 647 instead of 537 MB per launch of 1024 tiles) */
+template <bool SW_OUT, bool NT_OUT>
 __global__ void __launch_bounds__(512, 1)
 pass3q_kernel(const P3SArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
@@ -145,14 +149,12 @@ pass3q_kernel(const P3SArgs a) {
 
     /* ---- stage C: DFT-32 over a2, store X[q][d1 + 8 d2 + 128 c] */
     RB<R3>::run(z);
-    const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
-    const bool nt_out = (a.flags & FFTW_AMD_F_NT_OUT) != 0;
     double *p = dst + (i64)cq * a.drs + 2 * (cd1 + RA * cd2);
 #pragma unroll
     for (int c = 0; c < R3; ++c) {
         cplx v = z[RB<R3>::slot(c)];
-        if (sw) { double t = v.x; v.x = v.y; v.y = t; }
-        st_sel(p + (i64)c * (2 * RA * R2), v, nt_out);
+        if (SW_OUT) { double t = v.x; v.x = v.y; v.y = t; }
+        st_cplx<NT_OUT>(p + (i64)c * (2 * RA * R2), v);
     }
 }
 

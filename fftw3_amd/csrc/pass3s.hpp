@@ -63,7 +63,9 @@ struct P3SArgs {
    apart, the tile index runs over dims[0] -- and a DFT of length T across them (no twiddle) is taken in the same
    registers: every tile is transformed as a 2-D array T x L.  The last trip of a two-dimensional transform whose
    strided axis is T x L0 (planner.c emit_rows_lo_dft; pass3q.hpp is the 512-item form for four rows of 4096). */
-template <int R1, int MODE = 0, bool XROW = false>
+/* OUTF >= 0: FFTW_AMD_F_SWAP_OUT (bit 0) and FFTW_AMD_F_NT_OUT (bit 1) of the step as compile-time constants (the XROW
+   launcher instantiates the four combinations); -1: read from a.flags */
+template <int R1, int MODE = 0, bool XROW = false, int OUTF = -1>
 __global__ void __launch_bounds__(256, 2)
 pass3s_kernel(const P3SArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
@@ -209,7 +211,8 @@ pass3s_kernel(const P3SArgs a) {
         for (int q = 0; q < 16; ++q) z[v][q].y = plane[(ct[v] * 16 + cd2[v]) * SD2 + q * A2S + cd1[v]];
 
     /* ---- stage C: DFT-16 over a2, store X[d1 + R1 d2 + 16 R1 c] */
-    const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
+    const bool sw = OUTF >= 0 ? (OUTF & 1) != 0 : (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
+    const bool nt_out = OUTF >= 0 ? (OUTF & 2) != 0 : (a.flags & FFTW_AMD_F_NT_OUT) != 0;
     if (MODE == 1) {
         constexpr int L = G::L;
 #pragma unroll
@@ -287,7 +290,7 @@ pass3s_kernel(const P3SArgs a) {
             for (int c = 0; c < 16; ++c) {
                 cplx w = z[v][c];
                 if (sw) { double s = w.x; w.x = w.y; w.y = s; }
-                st_sel(p + (i64)c * (32 * R1), w, (a.flags & FFTW_AMD_F_NT_OUT) != 0);
+                st_sel(p + (i64)c * (32 * R1), w, nt_out);
             }
         }
     }

@@ -29,7 +29,9 @@ struct P3WGeom {
 
 /* MODE 0: complex rows; MODE 1: real rows of 32768 -> half spectra; MODE 2: half spectra -> real rows (the fused
    untangle / tangle of pass3s_kernel, pass3s.hpp) */
-template <int MODE>
+/* SW_OUT / NT_OUT (MODE 0: FFTW_AMD_F_SWAP_OUT / NT_OUT of the step) are compile-time: as run-time branches around
+   the 32 stores they cost 20 spilled VGPRs in the last butterfly (see pass3q.hpp) */
+template <int MODE, bool SW_OUT = false, bool NT_OUT = false>
 __global__ void __launch_bounds__(512, 1)
 pass3w_kernel(const P3SArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
@@ -167,14 +169,13 @@ pass3w_kernel(const P3SArgs a) {
         }
         return;
     }
-    const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
     double *p = dst + 2 * (cd1 + R1 * cd2);
 #pragma unroll
     for (int c = 0; c < R3; ++c) {
         cplx v = z[RB<R3>::slot(c)];
         if (MODE == 2) { *reinterpret_cast<cplx *>(p + (i64)c * (2 * R1 * R2)) = c_make(v.y, v.x); continue; }
-        if (sw) { double s = v.x; v.x = v.y; v.y = s; }
-        st_sel(p + (i64)c * (2 * R1 * R2), v, (a.flags & FFTW_AMD_F_NT_OUT) != 0);
+        if (SW_OUT) { double s = v.x; v.x = v.y; v.y = s; }
+        st_cplx<NT_OUT>(p + (i64)c * (2 * R1 * R2), v);
     }
 }
 
