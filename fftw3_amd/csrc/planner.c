@@ -1191,7 +1191,7 @@ static int emit_rows_lo_dft(plan *p, fa_loc in, fa_loc out, int sw_in, int sw_ou
     int nd, sbuf;
     i64 N1, N0, T = 0, L0, img, chunk = p->hrank ? p->chunk : 1;
     fftw_amd_step_desc *st;
-    if (p->rank != 2 || p->hrank > 1 || getenv("FFTW_AMD_NO_TUNED") || getenv("FFTW_AMD_NO_LO_DFT")) return 0;
+    if (p->rank != 2 || p->hrank > 1 || getenv("FFTW_AMD_NO_TUNED") || getenv("FFTW_AMD_NO_LO_DFT") || getenv("FFTW_AMD_NO_3S")) return 0;
     N1 = row->n; N0 = col->n;
     if ((N1 != 2048 && N1 != 4096) || N0 <= 1024 || N0 > 4096) return 0;
     if (N1 == 4096 && N0 <= 2048 && N0 % 2 == 0 && has_register_kernel(N0 / 2)) T = 2;      /* pass3s<16>, XROW */
