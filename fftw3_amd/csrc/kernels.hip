@@ -1306,19 +1306,10 @@ extern "C" int fa_hip_launch_pair1024(const fftw_amd_step_desc *d_second, double
     return 0;
 }
 
-int fa_launch_rows1024_3s(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
-                          i64 cs, i64 cn, hipStream_t st);       /* kernels_sq.hip */
-
 static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                        i64 cs, i64 cn, hipStream_t st) {
     PassArgs pa;
     if (d->flags & (FFTW_AMD_F_R2C_ROWS | FFTW_AMD_F_C2R_ROWS)) return fa_launch_r2crows(d, bufs, tables, cs, cn, st);
-    if (d->variant == FFTW_AMD_K_P1024 && d->tw_n == 0 && d->is_l == 2 && d->os_l == 2) {
-        /* contiguous rows of 1024 points: the three-stage rows kernel (experiment switch FFTW_AMD_ROWS1024_3S) */
-        static int rows3s = -1;
-        if (rows3s < 0) { const char *e = getenv("FFTW_AMD_ROWS1024_3S"); rows3s = e ? atoi(e) : 0; }
-        if (rows3s && fa_launch_rows1024_3s(d, bufs, tables, cs, cn, st) == 0) return 0;
-    }
     if (d->variant == FFTW_AMD_K_P1024 && launch_p1024(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_BLUE) return fa_launch_blue(d, bufs, tables, cs, cn, st);
     if (d->variant == FFTW_AMD_K_R1 && fa_launch_pass1r(d, bufs, tables, cs, cn, st) == 0) return 0;

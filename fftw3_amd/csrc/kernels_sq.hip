@@ -81,42 +81,3 @@ int fa_launch_lo_dft(const fftw_amd_step_desc *d, double *const *bufs, void *con
     }
     return 0;
 }
-
-/* Contiguous rows of 1024 points on the three-stage rows kernel (4 x 16 x 16, eight rows per tile) in the place of
-   the 32 x 32 kernel of pass1024.hpp: 1 = not applicable (strided forms, twiddles, unaligned arrays keep pass1024). */
-int fa_launch_rows1024_3s(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
-                          i64 cs, i64 cn, hipStream_t st) {
-    P3SArgs pa = P3SArgs();
-    int bd = d->batch_dim;
-    i64 sbase = d->src_base, dbase = d->dst_base;
-    if (d->L != 1024 || d->src_im != 1 || d->dst_im != 1 || d->tw_n || d->is_l != 2 || d->os_l != 2 || d->tile_lo_n > 1 ||
-        (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT | FFTW_AMD_F_LO_DFT)))
-        return 1;
-    for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
-        pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
-        pa.dis[i] = (i < d->ndims) ? d->dim_is[i] : 0;
-        pa.dos[i] = (i < d->ndims) ? d->dim_os[i] : 0;
-        if (i < d->ndims && ((pa.dis[i] % 2) || (pa.dos[i] % 2))) return 1;
-    }
-    if (bd >= 0) {
-        sbase += chunk_adv(d->src_buf, cs, d->dim_is[bd]);
-        dbase += chunk_adv(d->dst_buf, cs, d->dim_os[bd]);
-        pa.dn[bd] = cn;
-    }
-    pa.src = bufs[d->src_buf] + sbase;
-    pa.dst = bufs[d->dst_buf] + dbase;
-    if (((uintptr_t)pa.src % 16) || ((uintptr_t)pa.dst % 16)) return 1;
-    /* rows must be the tile dim: whole rows, one after the other at any even pitch */
-    if (pa.dn[0] < 8) return 1;
-    pa.wL = (const cplx *)tables[d->table];
-    pa.ndims = d->ndims;
-    pa.flags = d->flags;
-    pa.ntiles = (pa.dn[0] + 7) / 8;
-    i64 nblocks = pa.ntiles;
-    for (int i = 1; i < d->ndims; ++i) nblocks *= pa.dn[i];
-    if (nblocks <= 0) return 0;
-    if (nblocks > 0x7fffffffLL) return 1;
-    static std::atomic<unsigned> a4{0};
-    launch_sq(pass3s_kernel<4, 0, false>, a4, P3SGeom<4>::lds_doubles * sizeof(double), (unsigned)nblocks, 256, st, pa);
-    return 0;
-}
