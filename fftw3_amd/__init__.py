@@ -146,6 +146,14 @@ _sig("fftw_amd_plan_many_dft_c2r_sharded", _vp, C.c_int, _ip, C.c_int, C.c_int, 
 _sig("fftw_amd_execute_sharded", None, _vp)
 _sig("fftw_amd_sharded_sync", None, _vp)
 _sig("fftw_amd_sharded_all_gather", C.c_int, _vp, _vpp, C.c_int)
+_sig("fftw_amd_slab_local_size", C.c_longlong, C.c_int, C.POINTER(C.c_longlong), C.c_int, C.c_int,
+     C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
+_sig("fftw_amd_slab_plan_dft", _vp, C.c_int, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int), _vpp, _vpp, C.c_int, C.c_uint)
+_sig("fftw_amd_slab_execute", None, _vp)
+_sig("fftw_amd_slab_sync", None, _vp)
+_sig("fftw_amd_slab_num_devices", C.c_int, _vp)
+_sig("fftw_amd_slab_local_plan", _vp, _vp, C.c_int, C.c_int)
+_sig("fftw_amd_destroy_slab_plan", None, _vp)
 _sig("fftw_amd_sharded_gather_ops", C.c_int, _vp, _vpp, C.POINTER(C.c_longlong), C.c_int)
 _sig("fftw_amd_rccl_probe", C.c_int)
 _sig("fftw_amd_plan_workspace_device", C.c_int, _vp)
@@ -640,3 +648,54 @@ def import_wisdom_from_string(s):
 
 def forget_wisdom():
     lib.fftw_forget_wisdom()
+
+
+# ---- one transform in slabs over the GPUs of this process (fftw3_amd/csrc/slab.c; the multi-process form is slab.py)
+
+def slab_local_size(n, ndev, g):
+    """fftw_amd_slab_local_size: (elements, local_n0, local_0_start) of device g"""
+    nn = (C.c_longlong * len(n))(*n)
+    ln0, lo = C.c_longlong(0), C.c_longlong(0)
+    tot = lib.fftw_amd_slab_local_size(len(n), nn, ndev, g, C.byref(ln0), C.byref(lo))
+    return tot, ln0.value, lo.value
+
+
+class SlabPlanC(object):
+    """fftw_amd_slab_plan_dft: a 2-D / 3-D complex transform whose first dimension is cut over several devices"""
+
+    def __init__(self, n, devs, ins, outs, sign, flags=ESTIMATE):
+        nn = (C.c_longlong * len(n))(*n)
+        dv = (C.c_int * len(devs))(*devs)
+        self.handle = lib.fftw_amd_slab_plan_dft(len(n), nn, len(devs), dv, _ptrs(ins), _ptrs(outs), sign, flags)
+        if not self.handle:
+            raise ValueError("slab planner returned NULL (invalid or unsupported problem)")
+        self._keep = (ins, outs)
+
+    def execute(self):
+        if device_count() <= 0:
+            raise RuntimeError("no HIP device: the slab plan cannot execute (no CPU fallback)")
+        lib.fftw_amd_slab_execute(self.handle)
+
+    def sync(self):
+        lib.fftw_amd_slab_sync(self.handle)
+
+    def local_plan_sprint(self, g, which):
+        h = lib.fftw_amd_slab_local_plan(self.handle, g, which)
+        if not h:
+            return None
+        s = lib.fftw_sprint_plan(h)
+        try:
+            return C.cast(s, C.c_char_p).value.decode()
+        finally:
+            lib.fftw_free(s)
+
+    def destroy(self):
+        if self.handle:
+            lib.fftw_amd_destroy_slab_plan(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -46,6 +46,9 @@ int   fa_hip_get_device(void);
 void  fa_hip_set_device(int dev);                   /* of the calling host thread */
 int   fa_hip_enable_peer(int dev, int peer);        /* 0: dev may address peer's memory */
 void  fa_hip_memcpy_peer(void *dst, int dst_dev, const void *src, int src_dev, size_t nbytes, void *stream);
+/* 2-D device-to-device copy (rows of `width` bytes, `height` of them), source and destination possibly on different
+   devices with peer access; asynchronous on `stream` (a stream of the current device) */
+void  fa_hip_memcpy2d_peer(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, void *stream);
 
 /* Launch one step.  bufs[i] is the device base pointer of buffer id i, tables[i]
    the device pointer of table id i.  (chunk_start, chunk_n) select the slice

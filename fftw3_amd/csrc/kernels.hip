@@ -1111,6 +1111,10 @@ extern "C" void fa_hip_memcpy_peer(void *dst, int dst_dev, const void *src, int 
     if (dst_dev == src_dev) FA_CHECK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     else FA_CHECK(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, n, (hipStream_t)stream));
 }
+extern "C" void fa_hip_memcpy2d_peer(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, void *stream) {
+    if (!width || !height) return;
+    FA_CHECK(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+}
 extern "C" void fa_hip_stream_wait_event(void *s, void *ev) {
     FA_CHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0));
 }

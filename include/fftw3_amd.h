@@ -112,6 +112,28 @@ void fftw_amd_sharded_range(const fftw_amd_sharded_plan p, int g, long long *lo,
 fftw_plan fftw_amd_sharded_replica(const fftw_amd_sharded_plan p, int g);   /* NULL for an empty shard */
 void fftw_amd_destroy_sharded_plan(fftw_amd_sharded_plan p);
 
+/* ---- one transform spread over the GPUs of a node in slabs ----------------------
+   The c2c part of the reference's distributed-memory API (fftw/mpi/fftw3-mpi.h:74-215: fftw_mpi_local_size_2d / _3d,
+   fftw_mpi_plan_dft_2d / _3d, fftw_mpi_execute_dft) with the MPI communicator replaced by a list of devices of this
+   process: device g of ndev owns the rows [local_0_start, local_0_start + local_n0) of the first dimension (block
+   rule of fftw/mpi/block.c:39-50), normal order in and out.  Pipeline: local transforms over the trailing
+   dimension(s), exchange of column blocks (peer-to-peer 2-D copies over xGMI on the receiver's stream), local
+   transforms of length n0 down the column blocks, exchange back (fftw3_amd/csrc/slab.c).  The multi-process form of
+   the same layer -- r2c / c2r / r2r, TRANSPOSED_IN / OUT, torch.distributed in the place of MPI -- is
+   fftw3_amd/slab.py. */
+typedef struct fftw_amd_slab_plan_s *fftw_amd_slab_plan;
+/* rows of device g (rank = 2 or 3, n = the logical size); returns the number of complex elements of its arrays */
+long long fftw_amd_slab_local_size(int rank, const long long *n, int ndev, int g, long long *local_n0, long long *local_0_start);
+/* in[g] / out[g]: device arrays on devs[g] (devs == NULL: 0..ndev-1) with local_n0(g) x n[1] (x n[2]) complex values;
+   in[g] == out[g] is allowed.  NULL on invalid arguments or when a local plan / buffer cannot be made. */
+fftw_amd_slab_plan fftw_amd_slab_plan_dft(int rank, const long long *n, int ndev, const int *devs,
+                                          fftw_complex *const *in, fftw_complex *const *out, int sign, unsigned flags);
+void fftw_amd_slab_execute(fftw_amd_slab_plan p);      /* enqueues on every device and returns */
+void fftw_amd_slab_sync(fftw_amd_slab_plan p);
+int  fftw_amd_slab_num_devices(const fftw_amd_slab_plan p);
+fftw_plan fftw_amd_slab_local_plan(const fftw_amd_slab_plan p, int g, int which);   /* 0: rows plan, 1: column-block plan */
+void fftw_amd_destroy_slab_plan(fftw_amd_slab_plan p);
+
 /* ---- plan introspection used by the host-logic tests ------------------- */
 
 #define FFTW_AMD_MAX_DIMS 8
