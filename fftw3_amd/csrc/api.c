@@ -107,6 +107,7 @@ static plan *clone_problem(const plan *p, fa_cfg c) {
     for (i = 0; i < p->hrank; ++i) q->hdims[i] = p->hdims[i];
     q->in_im = p->in_im; q->out_im = p->out_im;
     q->single_chunk = p->single_chunk;
+    q->via_scratch = p->via_scratch;
     q->cfg = c;
     return q;
 }
@@ -251,6 +252,45 @@ static int inplace_ok_c2c(const plan *p) {
     return 1;
 }
 
+/* In-place problems whose input and output strides differ are still legal in the reference when both stride sets
+   address the SAME locations (fftw_tensor_inplace_locations, A.c:17298-17311: the transform and vector dims, taken
+   once with the input and once with the output strides, compress to equal tensors) -- in-place transposes and
+   transposed-output transforms, which the reference plans with its square DIF + transpose codelets
+   (dft-ct-dif + dftw-directsq "q1_r", A.c:2204-2250, 2596-2727) or buffers.  Same test here: sort the (n, |stride|)
+   pairs of each side by stride, merge contiguous runs, compare. */
+static int locs_compress(const plan *p, int use_os, i64 *n, i64 *st) {
+    int i, j, k = 0;
+    for (i = 0; i < p->rank + p->hrank; ++i) {
+        const fa_dim *d = i < p->rank ? &p->dims[i] : &p->hdims[i - p->rank];
+        i64 s = use_os ? d->os : d->is;
+        if (d->n == 1) continue;
+        n[k] = d->n; st[k] = s < 0 ? -s : s; ++k;
+    }
+    for (i = 1; i < k; ++i)                       /* insertion sort by stride */
+        for (j = i; j > 0 && st[j] < st[j - 1]; --j) {
+            i64 t = st[j]; st[j] = st[j - 1]; st[j - 1] = t;
+            t = n[j]; n[j] = n[j - 1]; n[j - 1] = t;
+        }
+    for (i = 0, j = 0; i < k; ++i) {              /* merge: next stride == n * stride */
+        if (j > 0 && st[i] == n[j - 1] * st[j - 1]) n[j - 1] *= n[i];
+        else { n[j] = n[i]; st[j] = st[i]; ++j; }
+    }
+    return j;
+}
+static int inplace_same_locations(const plan *p) {
+    i64 ni[2 * FA_MAXRANK], si[2 * FA_MAXRANK], no[2 * FA_MAXRANK], so[2 * FA_MAXRANK];
+    int i, ki, ko;
+    for (i = 0; i < p->rank + p->hrank; ++i) {
+        const fa_dim *d = i < p->rank ? &p->dims[i] : &p->hdims[i - p->rank];
+        if (d->n > 1 && (d->is < 0 || d->os < 0)) return 0;      /* mirrored layouts: not taken on */
+    }
+    ki = locs_compress(p, 0, ni, si);
+    ko = locs_compress(p, 1, no, so);
+    if (ki != ko) return 0;
+    for (i = 0; i < ki; ++i) if (ni[i] != no[i] || si[i] != so[i]) return 0;
+    return 1;
+}
+
 /* move the loop with the largest stride to hdims[0]: it is the chunked batch */
 static void pick_batch(plan *p) {
     int i, best = 0;
@@ -309,7 +349,13 @@ static plan *mk_guru(int type, int rank, const fftw_iodim64 *dims, int hrank,
     pick_batch(p);
     p->in_im = (type == FA_R2C) ? 0 : (i64)(ii - ri);
     p->out_im = (type == FA_C2R) ? 0 : (i64)(io - ro);
-    if (type == FA_C2C && ri == ro && !inplace_ok_c2c(p)) { fa_plan_free(p); return NULL; }
+    if (type == FA_C2C && ri == ro && !inplace_ok_c2c(p)) {
+        /* strides differ: legal when both sides address the same locations; the whole problem then goes through a
+           dense scratch image (every read before every write), in one chunk */
+        if (ii != io || !inplace_same_locations(p)) { fa_plan_free(p); return NULL; }
+        p->via_scratch = 1;
+        p->single_chunk = 1;
+    }
     if (type != FA_C2C && (void *)ri == (void *)ro) {
         /* in-place real transforms always pass through scratch; when the two
            layouts do not advance together per batch element, run the whole

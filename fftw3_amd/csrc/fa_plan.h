@@ -114,6 +114,8 @@ struct fftw_plan_s {
     i64 out_written;            /* number of doubles the plan writes in the output */
     int inplace;
     int single_chunk;           /* run the whole batch as one chunk */
+    int via_scratch;            /* in-place c2c problem whose input and output strides differ (same locations): the
+                                   result is built in a dense scratch image and copied to the output layout */
 
     void *stream;
     int dev_ready;

@@ -1234,11 +1234,54 @@ static int emit_rows_lo_dft(plan *p, fa_loc in, fa_loc out, int sw_in, int sw_ou
     return 1;
 }
 
+static void build_c2c_on(plan *p, fa_loc in, fa_loc out);
+
 static void build_c2c(plan *p) {
+    fa_loc in = { 0, 0, p->in_im }, out = { 1, 0, p->out_im };
+    if (p->via_scratch) {
+        /* in-place with different strides on the two sides (same locations): transform into a dense row-major
+           scratch image [hdims...][dims...], then copy it to the output layout -- every read of the user's array
+           precedes every write (single chunk).  The reference does these problems with its in-place square
+           DIF + transpose codelets or with buffers (A.c:2204-2250, 2596-2727); see api.c inplace_same_locations. */
+        fa_dim sd[FA_MAXRANK], sh[FA_MAXRANK];
+        fa_loc scr;
+        fa_axis ax;
+        sdim d[FA_MAXLOOPS];
+        i64 stride = 2, total;
+        int i, nd, sbuf;
+        memcpy(sd, p->dims, sizeof(sd));
+        memcpy(sh, p->hdims, sizeof(sh));
+        for (i = p->rank - 1; i >= 0; --i) { p->dims[i].os = stride; stride *= p->dims[i].n; }
+        for (i = p->hrank - 1; i >= 0; --i) {
+            p->hdims[i].os = stride;
+            stride *= (i == 0 ? p->chunk : p->hdims[i].n);
+        }
+        total = stride;
+        sbuf = buf_acquire(p, total);
+        scr.buf = sbuf; scr.base = 0; scr.im = 1;
+        build_c2c_on(p, in, scr);
+        /* the copy: all dims as loops, source = dense strides, destination = the user's output strides */
+        memset(&ax, 0, sizeof(ax));
+        for (i = 0; i < p->rank; ++i) p->dims[i].is = p->dims[i].os;
+        for (i = 0; i < p->hrank; ++i) p->hdims[i].is = p->hdims[i].os;
+        for (i = 0; i < p->rank; ++i) p->dims[i].os = sd[i].os;
+        for (i = 0; i < p->hrank; ++i) p->hdims[i].os = sh[i].os;
+        if (!p->failed && collect_loops(p, p->dims, p->rank, -1, NULL, 0, &ax) == 0) {
+            nd = loops_to_sdims(&ax, d, 0);
+            emit_pass(p, scr, out, 1, 0, 0, d, nd, 0, 0);
+        } else p->failed = 1;
+        memcpy(p->dims, sd, sizeof(sd));
+        memcpy(p->hdims, sh, sizeof(sh));
+        buf_release(p, sbuf);
+        return;
+    }
+    build_c2c_on(p, in, out);
+}
+
+static void build_c2c_on(plan *p, fa_loc in, fa_loc out) {
     int a, first = 1;
     int sw_in = (p->sign > 0) ? FFTW_AMD_F_SWAP_IN : 0;
     int sw_out = (p->sign > 0) ? FFTW_AMD_F_SWAP_OUT : 0;
-    fa_loc in = { 0, 0, p->in_im }, out = { 1, 0, p->out_im };
     if (p->rank == 0) {
         /* rank-0 "transform" = strided copy (reference rank0 solvers) */
         fa_axis ax;

@@ -618,6 +618,41 @@ def test_rows_with_a_dft_across_the_rows_of_a_tile(torch_dev, n0, n1, t):
         assert aerror(yd.cpu().numpy(), oracle_dft(x, (n0, n1), 3, sign).reshape(3, n0 * n1)) < TOL
 
 
+def test_inplace_with_different_strides_on_the_two_sides(torch_dev):
+    """in-place problems whose input and output strides differ but address the same locations (the reference's
+    fftw_tensor_inplace_locations rule, A.c:17298-17311; its own plans: dft-ct-dif + "q1_r" square codelets,
+    A.c:2204-2250): transposed-output batched transforms, a rank-0 transpose and a 2-D transform with exchanged
+    output axes, on the GPU against the oracle; also on plain host arrays (staged)."""
+    torch, dev = torch_dev
+    rng = np.random.default_rng(171)
+    for n, v in ((64, 64), (48, 80), (1024, 16), (4096, 3), (1 << 16, 4)):
+        x = crand(rng, 1, n * v).reshape(-1)
+        xd = torch.from_numpy(x).to(dev)
+        p = fa.plan_guru64_dft([(n, 1, v)], [(v, n, 1)], xd, xd, fa.FORWARD)
+        p.execute()
+        torch.cuda.synchronize()
+        want = oracle_dft(x.reshape(1, -1), (n,), v).reshape(v, n).T.reshape(-1)
+        assert aerror(xd.cpu().numpy(), want) < TOL, (n, v)
+        # new-array execution on another in-place buffer
+        x2 = crand(rng, 1, n * v).reshape(-1)
+        x2d = torch.from_numpy(x2).to(dev)
+        p.execute_dft(x2d, x2d)
+        torch.cuda.synchronize()
+        assert aerror(x2d.cpu().numpy(), oracle_dft(x2.reshape(1, -1), (n,), v).reshape(v, n).T.reshape(-1)) < TOL
+    n0, n1 = 1200, 2000
+    x = crand(rng, 1, n0 * n1).reshape(-1)
+    xd = torch.from_numpy(x).to(dev)
+    fa.plan_guru64_dft([], [(n0, n1, 1), (n1, 1, n0)], xd, xd, fa.FORWARD).execute()
+    torch.cuda.synchronize()
+    assert np.array_equal(xd.cpu().numpy().reshape(n1, n0), x.reshape(n0, n1).T)
+    a, b = 240, 400
+    x = crand(rng, 1, a * b).reshape(-1)
+    xh = x.copy()                                                    # host array: staged in place
+    fa.plan_guru64_dft([(a, b, 1), (b, 1, a)], [], xh, xh, fa.BACKWARD).execute()
+    want = oracle_dft(x.reshape(1, -1), (a, b), 1, 1).reshape(a, b).T.reshape(-1)
+    assert aerror(xh, want) < TOL
+
+
 def test_mixed_radix_baseline_size_against_oracle(torch_dev):
     """cfg4 unit: N = 3*5*7*11*13*2^10, one transform against the oracle"""
     n = 3 * 5 * 7 * 11 * 13 * 1024

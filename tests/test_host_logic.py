@@ -523,3 +523,38 @@ def test_one_trip_rows_plans():
         yy = ref.copy()
         run_plan_on_host(q, yy, z)
         assert aerror(z, xr * n) < TOL, n
+
+
+def test_inplace_problems_with_different_strides_on_the_two_sides():
+    """the reference accepts an in-place problem whose input and output strides differ as long as both address the
+    same locations (fftw_tensor_inplace_locations, fftw/fftw_api.c:17298-17311; its planner then uses the in-place
+    square DIF + transpose codelets "q1_r" or buffers, :2204-2250, :2596-2727): transposed-output transforms and
+    rank-0 transposes.  Here such a plan runs through a dense scratch image in one chunk; step lists under the
+    numpy interpreter."""
+    rng2 = np.random.default_rng(17)
+    for n, v in ((64, 64), (48, 80), (7, 5), (1024, 16), (4096, 3)):
+        x = crand(rng2, 1, n * v).reshape(-1)
+        x0 = x.copy()
+        p = fa.plan_guru64_dft([(n, 1, v)], [(v, n, 1)], x, x, fa.FORWARD)      # in[b n + j] -> out[k v + b]
+        assert p.batch == p.chunk                                              # one chunk: reads before writes
+        run_plan_on_host(p, x, x)
+        want = oracle_dft(x0.reshape(1, -1), (n,), v).reshape(v, n).T.reshape(-1)
+        assert aerror(x, want) < TOL, (n, v)
+    # rank 0: an in-place transpose, non-square
+    n0, n1 = 12, 20
+    x = crand(rng2, 1, n0 * n1).reshape(-1)
+    x0 = x.copy()
+    p = fa.plan_guru64_dft([], [(n0, n1, 1), (n1, 1, n0)], x, x, fa.FORWARD)
+    run_plan_on_host(p, x, x)
+    assert np.array_equal(x.reshape(n1, n0), x0.reshape(n0, n1).T)
+    # 2-D in place with the two output axes exchanged
+    a, b = 24, 40
+    x = crand(rng2, 1, a * b).reshape(-1)
+    x0 = x.copy()
+    p = fa.plan_guru64_dft([(a, b, 1), (b, 1, a)], [], x, x, fa.BACKWARD)
+    run_plan_on_host(p, x, x)
+    want = oracle_dft(x0.reshape(1, -1), (a, b), 1, 1).reshape(a, b).T.reshape(-1)
+    assert aerror(x, want) < TOL
+    # different locations on the two sides stay rejected (A.c:4090-4094)
+    with pytest.raises(ValueError):
+        fa.plan_guru64_dft([(8, 1, 2)], [], x[:16], x[:16], fa.FORWARD)
