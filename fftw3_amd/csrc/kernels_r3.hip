@@ -24,11 +24,14 @@ static void launch_3g(const P3SArgs &pa, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((pass3g_kernel<R1, R2, R3>), grid, dim3(256), lds, st, pa);
 }
 
+extern "C" int fa_hip_r3w_has(int L);              /* kernels_r3w.hip */
+
 /* rows per tile of the three-stage kernel for length L (0: none).  2048 / 4096 / 8192 are the
    tuned pass3s kernels of kernels_rr.hip. */
 extern "C" int fa_hip_r3_tile(int L) {
     if (L == 2048 || L == 4096 || L == 8192) return 8192 / L;
     if (L == 16384) return 1;                      /* pass3w.hpp: one 512-item workgroup per row */
+    if (L > 8192 && fa_hip_r3w_has(L)) return 1;   /* kernels_r3w.hip: wide three-stage kernels, one row per 512-item workgroup */
     switch (L) {
 #define X(L_, R1_, R2_, R3_) case L_: return P3GGeom<R1_, R2_, R3_>::T;
 #include "r3_menu.inc"
@@ -44,7 +47,7 @@ int fa_launch_pass3g(const fftw_amd_step_desc *d, double *const *bufs, void *con
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
     const int T = fa_hip_r3_tile(d->L);
-    if (T <= 0 || d->L == 2048 || d->L == 4096 || d->L == 8192 || d->L == 16384 || d->tile != T || d->src_im != 1 || d->dst_im != 1 ||
+    if (T <= 0 || d->L == 2048 || d->L == 4096 || d->L == 8192 || d->L == 16384 || (d->L > 8192 && fa_hip_r3w_has(d->L)) || d->tile != T || d->src_im != 1 || d->dst_im != 1 ||
         d->tw_n || d->is_l != 2 || d->os_l != 2 || d->tile_lo_n > 1 ||
         (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
         return 1;

@@ -31,23 +31,26 @@
 #ifndef FA_PASS3G_HPP
 #define FA_PASS3G_HPP
 
-constexpr int fa_3g_q(int nb) { return (nb + 255) / 256; }
-/* rows per tile: as many as fit 8192 elements with at most 32 elements per item in every stage */
-constexpr int fa_3g_tile(int R1, int R2, int R3) {
+/* NT = work-items per workgroup: 256 (tiles of 8192 elements, two workgroups per CU) or, for the rows of
+   8193 ... 16384 points of r3w_menu.inc (round 3, kernels_r3w.hip), 512 (one row of up to 16384 elements per
+   workgroup, one workgroup per CU, like pass3w.hpp) */
+constexpr int fa_3g_q(int nb, int nt = 256) { return (nb + nt - 1) / nt; }
+/* rows per tile: as many as fit 32 NT elements with at most 32 elements per item in every stage */
+constexpr int fa_3g_tile(int R1, int R2, int R3, int nt = 256) {
     const int L = R1 * R2 * R3;
-    int T = 8192 / L;
+    int T = (32 * nt) / L;
     if (T < 1) T = 1;
-    while (T > 1 && (fa_3g_q(T * R2 * R3) * R1 > 32 || fa_3g_q(T * R1 * R3) * R2 > 32 ||
-                     fa_3g_q(T * R1 * R2) * R3 > 32)) --T;
+    while (T > 1 && (fa_3g_q(T * R2 * R3, nt) * R1 > 32 || fa_3g_q(T * R1 * R3, nt) * R2 > 32 ||
+                     fa_3g_q(T * R1 * R2, nt) * R3 > 32)) --T;
     return T;
 }
 
-template <int R1, int R2, int R3> struct P3GGeom {
+template <int R1, int R2, int R3, int NT = 256> struct P3GGeom {
     static constexpr int L = R1 * R2 * R3;
     static constexpr int M = R2 * R3;
-    static constexpr int T = fa_3g_tile(R1, R2, R3);
+    static constexpr int T = fa_3g_tile(R1, R2, R3, NT);
     static constexpr int NBA = T * M, NBB = T * R1 * R3, NBC = T * R1 * R2;
-    static constexpr int QA = fa_3g_q(NBA), QB = fa_3g_q(NBB), QC = fa_3g_q(NBC);
+    static constexpr int QA = fa_3g_q(NBA, NT), QB = fa_3g_q(NBB, NT), QC = fa_3g_q(NBC, NT);
     static constexpr bool fits = QA * R1 <= 32 && QB * R2 <= 32 && QC * R3 <= 32;
     static constexpr int S1 = M + (M % 2 == 0 ? 1 : 0);            /* E1 row stride, odd */
     static constexpr int A2S = R1 + (R1 % 2 == 0 ? 1 : 0);         /* E2 stride of a2, odd */
@@ -59,11 +62,11 @@ template <int R1, int R2, int R3> struct P3GGeom {
 
 /* MODE 0: complex rows; MODE 1: real rows of n = 2L -> half spectra; MODE 2: half spectra -> real rows -- the
    fused untangle / tangle of pass3s_kernel (pass3s.hpp) for the general factorisation */
-template <int R1, int R2, int R3, int MODE = 0>
-__global__ void __launch_bounds__(256, 2)
+template <int R1, int R2, int R3, int MODE = 0, int NT = 256>
+__global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1)
 pass3g_kernel(const P3SArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
-    typedef P3GGeom<R1, R2, R3> G;
+    typedef P3GGeom<R1, R2, R3, NT> G;
     constexpr int M = G::M, T = G::T, QA = G::QA, QB = G::QB, QC = G::QC;
     constexpr int S1 = G::S1, A2S = G::A2S, SD2 = G::SD2;
     const int tid = threadIdx.x;
@@ -80,7 +83,7 @@ pass3g_kernel(const P3SArgs a) {
     int at[QA], aa[QA];
 #pragma unroll
     for (int u = 0; u < QA; ++u) {
-        int g = u * 256 + tid;
+        int g = u * NT + tid;
         const int last = Tcur * M - 1;
         g = g < last ? g : last;                      /* beyond the tile: redo the last butterfly */
         at[u] = g / M;
@@ -124,7 +127,7 @@ pass3g_kernel(const P3SArgs a) {
     int ba2[QB], bd1[QB], bt[QB];
 #pragma unroll
     for (int v = 0; v < QB; ++v) {
-        int h = v * 256 + tid;
+        int h = v * NT + tid;
         const int last = Tcur * R1 * R3 - 1;
         h = h < last ? h : last;
         ba2[v] = h % R3;
@@ -167,7 +170,7 @@ pass3g_kernel(const P3SArgs a) {
     int cd1[QC], cd2[QC], ct[QC];
 #pragma unroll
     for (int w = 0; w < QC; ++w) {
-        int j = w * 256 + tid;
+        int j = w * NT + tid;
         const int last = Tcur * R1 * R2 - 1;
         j = j < last ? j : last;
         cd1[w] = j % R1;
@@ -259,6 +262,24 @@ pass3g_kernel(const P3SArgs a) {
     for (int w = 0; w < QC; ++w) {
         RB<R3>::run(z[w]);
         double *p = dst + (i64)ct[w] * a.dos[0] + 2 * (cd1[w] + R1 * cd2[w]);
+        if constexpr (NT > 256 && MODE == 0) {
+            /* one branch around the whole run of stores (a branch per store costs spilled VGPRs in the 512-item
+               kernels, see pass3q.hpp) */
+            if (a.flags & FFTW_AMD_F_NT_OUT) {
+#pragma unroll
+                for (int c = 0; c < R3; ++c) {
+                    cplx v = z[w][RB<R3>::slot(c)];
+                    st_cplx<true>(p + (i64)c * (2 * R1 * R2), sw ? c_make(v.y, v.x) : v);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < R3; ++c) {
+                    cplx v = z[w][RB<R3>::slot(c)];
+                    st_cplx<false>(p + (i64)c * (2 * R1 * R2), sw ? c_make(v.y, v.x) : v);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < R3; ++c) {
             cplx v = z[w][RB<R3>::slot(c)];

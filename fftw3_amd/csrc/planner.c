@@ -1017,9 +1017,10 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     /* 1024 < n <= 4096 that is not a power of two: two register-kernel passes (each near
        the copy rate) beat one pass of the LDS kernel (1.3-1.8 TB/s) whenever both halves of
        a balanced split have a register kernel -- measured n = 3000: 1.27 vs 2.4 TB/s */
-    /* 4096 < n <= 8192 with a three-stage rows kernel (one row per workgroup): one trip instead of two, under
-       the same plan-time conditions as the 8192-point rows (no LDS-kernel fallback at that length) */
-    if (contiguous && ax.n > FA_LMAX_SINGLE && ax.n <= 8192 && (ax.n & (ax.n - 1)) != 0 && ax.nloops > 0 &&
+    /* 4096 < n < 16384 with a three-stage rows kernel (one row per workgroup; above 8192 the 512-item kernels of
+       kernels_r3w.hip): one trip instead of two, under the same plan-time conditions as the 8192-point rows (no
+       LDS-kernel fallback at that length) */
+    if (contiguous && ax.n > FA_LMAX_SINGLE && ax.n < 16384 && (ax.n & (ax.n - 1)) != 0 && ax.nloops > 0 &&
         !getenv("FFTW_AMD_NO_TUNED") && !getenv("FFTW_AMD_NO_3S") && fa_hip_r3_tile((int)ax.n) > 0 &&
         long_rows_ok(p, &ax))
         lmax1 = ax.n;

@@ -128,6 +128,38 @@ def test_three_stage_rows_kernel(L, r1, r2, r3):
     assert aerror(xd.cpu().numpy(), oracle_dft(x, (L,), hm, sign=+1)) <= TOL, L
 
 
+def menu3w():
+    out = []
+    with open(os.path.join(ROOT, "fftw3_amd", "csrc", "r3w_menu.inc")) as f:
+        for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read()):
+            out.append(tuple(int(v) for v in m.groups()))
+    return out
+
+
+MENU3W = menu3w()
+
+
+@pytest.mark.parametrize("L,r1,r2,r3", MENU3W, ids=[str(m[0]) for m in MENU3W])
+def test_wide_three_stage_rows_kernel(L, r1, r2, r3):
+    """every wide three-stage rows kernel of r3w_menu.inc (round 3: rows of 8193 ... 16383 points, one row per
+    workgroup of 512 work-items, kernels_r3w.hip): forward out of place, backward in place (swap flags), against
+    the oracle; the plan is ONE step"""
+    import torch
+    assert r1 * r2 * r3 == L and 8192 < L < 16384
+    hm = 5
+    p, e = _run(L, hm, 1, L)
+    assert "pass-%d/reg3" % L in p.sprint() and len(p.steps()) == 1, p.sprint()
+    assert e <= TOL, (L, e)
+    rng = np.random.default_rng(L)
+    x = crand(rng, hm * L)
+    xd = torch.from_numpy(x).cuda()
+    q = fa.plan_many_dft(1, [L], hm, xd, None, 1, L, xd, None, 1, L, fa.BACKWARD)
+    assert len(q.steps()) == 1, q.sprint()
+    q.execute()
+    q.sync()
+    assert aerror(xd.cpu().numpy(), oracle_dft(x, (L,), hm, sign=+1)) <= TOL, L
+
+
 @pytest.mark.parametrize("L,r1,r2,r3", MENU3T, ids=[str(m[0]) for m in MENU3T])
 def test_three_stage_strided_forms(L, r1, r2, r3, monkeypatch):
     """every strided three-stage kernel of r3t_menu.inc in the four forms the planner emits:
