@@ -1138,6 +1138,8 @@ static void launch_pass_variant(const PassArgs &pa, dim3 grid, size_t lds, hipSt
 }
 
 /* kernels_rr.hip */
+int fa_launch_pass3tw(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
+                      i64 cs, i64 cn, hipStream_t st);          /* kernels_r3tw.hip */
 int fa_launch_pass3gw(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                       i64 cs, i64 cn, hipStream_t st);          /* kernels_r3w.hip */
 int fa_launch_pass3g(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
@@ -1321,6 +1323,7 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
     if (d->variant == FFTW_AMD_K_R1 && fa_launch_pass1r(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_RR && fa_launch_passrr(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_R3 && d->L > 8192 && d->L < 16384 && fa_launch_pass3gw(d, bufs, tables, cs, cn, st) == 0) return 0;
+    if (d->variant == FFTW_AMD_K_R3 && d->L > 1024 && d->L <= 2048 && fa_launch_pass3tw(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_R3 && (fa_launch_pass3s(d, bufs, tables, cs, cn, st) == 0 ||
                                         fa_launch_pass3g(d, bufs, tables, cs, cn, st) == 0 ||
                                         fa_launch_pass3t(d, bufs, tables, cs, cn, st) == 0)) return 0;

@@ -114,8 +114,12 @@ static int dispatch_3t(const P1024Args &pa, dim3 grid, hipStream_t st, bool in_t
     return 1;
 }
 
-/* sequences per tile of the strided three-stage kernel for length L (0: none) */
+extern "C" int fa_hip_r3tw_tile(int L);            /* kernels_r3tw.hip: the 512-item forms */
+
+/* sequences per tile of the strided three-stage kernel for length L (0: none); lengths with a 512-item form
+   (kernels_r3tw.hip) report that form's tile -- it is the one the executor launches */
 extern "C" int fa_hip_r3t_tile(int L) {
+    if (L > 1024 && fa_hip_r3tw_tile(L) > 0) return fa_hip_r3tw_tile(L);
     switch (L) {
 #define X(L_, R1_, R2_, R3_) case L_: return P3TGeom<R1_, R2_, R3_>::T;
 #include "r3t_menu.inc"
@@ -130,6 +134,7 @@ int fa_launch_pass3t(const fftw_amd_step_desc *d, double *const *bufs, void *con
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
     const int T = fa_hip_r3t_tile(d->L);
+    if (d->L > 1024 && fa_hip_r3tw_tile(d->L) > 0) return 1;      /* the 512-item form: fa_launch_pass3tw */
     if (T <= 0 || d->tile != T || d->src_im != 1 || d->dst_im != 1 || d->tile_lo_n > 1 ||
         (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT)))
         return 1;

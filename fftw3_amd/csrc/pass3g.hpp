@@ -298,12 +298,22 @@ pass3g_kernel(const P3SArgs a) {
 /* transposed store: IN_T = false, OUT_T = true) without twiddle or with it   */
 /* on the input (HAS_TW = 2).  Arguments are those of pass1024 (P1024Args).   */
 /* ------------------------------------------------------------------------ */
-template <int R1, int R2, int R3> struct P3TGeom {
+/* NT = 512 (round 3, kernels_r3tw.hip): tiles of 16384 elements, one workgroup per CU -- the lengths 1025 ... 2048 get
+   8 ... 15 sequences per tile (128 ... 240-byte segments) where the 256-item form has 4 ... 7 (64 ... 112 bytes) */
+constexpr int fa_3t_tile(int R1, int R2, int R3, int nt) {
+    const int L = R1 * R2 * R3;
+    int T = (32 * nt) / L;
+    if (nt == 256) return T;                                   /* the 256-item menu was chosen with exactly this tile */
+    while (T > 1 && (fa_3g_q(T * R2 * R3, nt) * R1 > 40 || fa_3g_q(T * R1 * R3, nt) * R2 > 40 ||
+                     fa_3g_q(T * R1 * R2, nt) * R3 > 40)) --T;
+    return T;
+}
+template <int R1, int R2, int R3, int NT = 256> struct P3TGeom {
     static constexpr int L = R1 * R2 * R3;
     static constexpr int M = R2 * R3;
-    static constexpr int T = 8192 / L;
+    static constexpr int T = fa_3t_tile(R1, R2, R3, NT);
     static constexpr int NBA = T * M, NBB = T * R1 * R3, NBC = T * R1 * R2;
-    static constexpr int QA = fa_3g_q(NBA), QB = fa_3g_q(NBB), QC = fa_3g_q(NBC);
+    static constexpr int QA = fa_3g_q(NBA, NT), QB = fa_3g_q(NBB, NT), QC = fa_3g_q(NBC, NT);
     static constexpr bool fits = T >= 4 && QA * R1 <= 40 && QB * R2 <= 40 && QC * R3 <= 40;   /* the menu keeps only spill-free ones; T = 4 (64-byte segments) only for 2048 */
     static constexpr int TP = T + 1;                               /* odd stride of t where it is not fastest */
     /* column form: element (d1, a, t) at (d1 * M + a) * T + t, rows of d1 padded to stride = T mod 32 */
@@ -316,11 +326,11 @@ template <int R1, int R2, int R3> struct P3TGeom {
     static constexpr int lds_doubles = (E1 > (E2C > E2R ? E2C : E2R) ? E1 : (E2C > E2R ? E2C : E2R)) + 16;
 };
 
-template <int R1, int R2, int R3, bool IN_T, int HAS_TW>
-__global__ void __launch_bounds__(256, 2)
+template <int R1, int R2, int R3, bool IN_T, int HAS_TW, int NT = 256>
+__global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1)
 pass3t_kernel(const P1024Args a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
-    typedef P3TGeom<R1, R2, R3> G;
+    typedef P3TGeom<R1, R2, R3, NT> G;
     constexpr int M = G::M, T = G::T, QA = G::QA, QB = G::QB, QC = G::QC;
     const int tid = threadIdx.x;
 
@@ -337,7 +347,7 @@ pass3t_kernel(const P1024Args a) {
     int at[QA], aa[QA];
 #pragma unroll
     for (int u = 0; u < QA; ++u) {
-        int g = u * 256 + tid;
+        int g = u * NT + tid;
         g = g < G::NBA - 1 ? g : G::NBA - 1;
         int t = IN_T ? g % T : g / M;
         aa[u] = IN_T ? g / T : g % M;
@@ -377,7 +387,7 @@ pass3t_kernel(const P1024Args a) {
     int ba2[QB], bd1[QB], bt[QB];
 #pragma unroll
     for (int v = 0; v < QB; ++v) {
-        int h = v * 256 + tid;
+        int h = v * NT + tid;
         h = h < G::NBB - 1 ? h : G::NBB - 1;
         if (IN_T) { bt[v] = h % T; ba2[v] = (h / T) % R3; bd1[v] = h / (T * R3); }
         else      { bd1[v] = h % R1; ba2[v] = (h / R1) % R3; bt[v] = h / (R1 * R3); }
@@ -422,7 +432,7 @@ pass3t_kernel(const P1024Args a) {
     int cd1[QC], cd2[QC], ct[QC];
 #pragma unroll
     for (int w = 0; w < QC; ++w) {
-        int j = w * 256 + tid;
+        int j = w * NT + tid;
         j = j < G::NBC - 1 ? j : G::NBC - 1;
         ct[w] = j % T;
         ct[w] = ct[w] < Tcur - 1 ? ct[w] : Tcur - 1;
@@ -469,6 +479,23 @@ pass3t_kernel(const P1024Args a) {
         }
         double *p = dst + (i64)kb * a.os_l + (i64)tc * a.dos[0];
         const i64 step = (i64)(R1 * R2) * a.os_l;
+        if constexpr (NT > 256) {
+            /* one branch around the run of stores, not one per store (spilled VGPRs in the 512-item kernels) */
+            if (a.flags & FFTW_AMD_F_NT_OUT) {
+#pragma unroll
+                for (int c = 0; c < R3; ++c) {
+                    cplx v = z[w][RB<R3>::slot(c)];
+                    st_cplx<true>(p + c * step, sw ? c_make(v.y, v.x) : v);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < R3; ++c) {
+                    cplx v = z[w][RB<R3>::slot(c)];
+                    st_cplx<false>(p + c * step, sw ? c_make(v.y, v.x) : v);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < R3; ++c) {
             cplx v = z[w][RB<R3>::slot(c)];
