@@ -41,7 +41,7 @@ $(CSRC)/kernels_r1.o: $(CSRC)/kernels_r1.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(C
 $(CSRC)/kernels_sq.o: $(CSRC)/kernels_sq.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass3q.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/kernels_r3w.o: $(CSRC)/kernels_r3w.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass3g.hpp $(CSRC)/r3w_menu.inc
+$(CSRC)/kernels_r3w.o: $(CSRC)/kernels_r3w.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass3g.hpp $(CSRC)/r3w_menu.inc $(CSRC)/r3rw_menu.inc
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/kernels_r3tw.o: $(CSRC)/kernels_r3tw.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass3g.hpp $(CSRC)/r3tw_menu.inc

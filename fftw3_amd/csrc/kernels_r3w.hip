@@ -77,3 +77,42 @@ int fa_launch_pass3gw(const fftw_amd_step_desc *d, double *const *bufs, void *co
     }
     return 1;
 }
+
+/* ---- fused real rows of n = 2L <-> half spectra for the wide half lengths of r3rw_menu.inc (MODE 1 / 2 of
+   pass3g_kernel at 512 work-items): real rows of 18 000 ... 30 720 points in ONE trip where round 2 ran a complex
+   pass plus an untangle / tangle step */
+template <int R1, int R2, int R3>
+static void launch_3gw_real(const P3SArgs &pa, dim3 grid, hipStream_t st, bool inverse) {
+    static std::atomic<unsigned> attr_done{0};
+    typedef P3GGeom<R1, R2, R3, 512> G;
+    static_assert(G::fits && G::T == 1, "wide real menu entry: one row per workgroup");
+    static_assert(G::lds_doubles * sizeof(double) <= 160 * 1024, "wide real menu entry exceeds the LDS");
+    const size_t lds = G::lds_doubles * sizeof(double);
+    if (fa_attr_needed(attr_done)) {
+        FA_CHECK(hipFuncSetAttribute((const void *)pass3g_kernel<R1, R2, R3, 1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FA_CHECK(hipFuncSetAttribute((const void *)pass3g_kernel<R1, R2, R3, 2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        fa_attr_set(attr_done);
+    }
+    const dim3 g512(512);
+    if (inverse) hipLaunchKernelGGL((pass3g_kernel<R1, R2, R3, 2, 512>), grid, g512, lds, st, pa);
+    else hipLaunchKernelGGL((pass3g_kernel<R1, R2, R3, 1, 512>), grid, g512, lds, st, pa);
+}
+
+extern "C" int fa_hip_r2c_rows3gw_has(int L) {
+    switch (L) {
+#define X(L_, R1_, R2_, R3_) case L_: return 1;
+#include "r3rw_menu.inc"
+#undef X
+    }
+    return 0;
+}
+
+/* pa, grid: filled by fa_launch_r2crows3 (kernels_rr.hip); 1 = no kernel for this length */
+int fa_launch_r2crows3gw(int L, const P3SArgs &pa, dim3 grid, hipStream_t st, bool inverse) {
+    switch (L) {
+#define X(L_, R1_, R2_, R3_) case L_: launch_3gw_real<R1_, R2_, R3_>(pa, grid, st, inverse); return 0;
+#include "r3rw_menu.inc"
+#undef X
+    }
+    return 1;
+}

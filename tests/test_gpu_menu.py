@@ -245,6 +245,17 @@ def menu3r():
 MENU3R = menu3r()
 
 
+def menu3rw():
+    out = []
+    with open(os.path.join(ROOT, "fftw3_amd", "csrc", "r3rw_menu.inc")) as f:
+        for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read()):
+            out.append(tuple(int(v) for v in m.groups()))
+    return out
+
+
+MENU3RW = menu3rw()        # round 3: half lengths 9000 ... 15360 on the 512-item kernels (kernels_r3w.hip)
+
+
 def menu2r():
     out = []
     with open(os.path.join(ROOT, "fftw3_amd", "csrc", "r2cr_menu.inc")) as f:
@@ -256,8 +267,8 @@ def menu2r():
 MENU2R = menu2r()
 
 
-@pytest.mark.parametrize("L,r1,r2,r3", MENU2R + MENU3R + [(2048, 8, 16, 16), (4096, 16, 16, 16), (8192, 32, 16, 16), (16384, 32, 16, 32)],
-                         ids=[str(m[0]) for m in MENU2R + MENU3R] + ["2048", "4096", "8192", "16384"])
+@pytest.mark.parametrize("L,r1,r2,r3", MENU2R + MENU3R + MENU3RW + [(2048, 8, 16, 16), (4096, 16, 16, 16), (8192, 32, 16, 16), (16384, 32, 16, 32)],
+                         ids=[str(m[0]) for m in MENU2R + MENU3R + MENU3RW] + ["2048", "4096", "8192", "16384"])
 def test_mixed_and_three_stage_real_rows(L, r1, r2, r3):
     """real rows of n = 2L in one trip -- the mixed-radix two-stage lengths of r2cr_menu.inc (r2crows.hpp) and the
     three-stage lengths (pass3g / pass3s MODE 1, 2): r2c with a ragged last tile against the oracle, c2r of the result
