@@ -9,7 +9,7 @@ LIBDIR := fftw3_amd/lib
 CFLAGS := -O2 -fPIC -std=gnu99 -Wall -Wextra -Iinclude -I$(CSRC)
 HIPFLAGS := -O3 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -std=c++17 -Wall
 
-OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/sharded.o $(CSRC)/slab.o $(CSRC)/hostmath.o $(CSRC)/kernels.o $(CSRC)/kernels_rr.o $(CSRC)/kernels_rr1.o $(CSRC)/kernels_rr2.o $(CSRC)/kernels_r3.o $(CSRC)/kernels_r3r.o $(CSRC)/kernels_r2cm.o $(CSRC)/kernels_blue.o $(CSRC)/kernels_r1.o $(CSRC)/kernels_sq.o $(CSRC)/kernels_r3w.o $(CSRC)/kernels_r3tw.o
+OBJS := $(CSRC)/api.o $(CSRC)/planner.o $(CSRC)/sharded.o $(CSRC)/slab.o $(CSRC)/hostmath.o $(CSRC)/kernels.o $(CSRC)/kernels_rr.o $(CSRC)/kernels_rr1.o $(CSRC)/kernels_rr2.o $(CSRC)/kernels_r3.o $(CSRC)/kernels_r3r.o $(CSRC)/kernels_r2cm.o $(CSRC)/kernels_blue.o $(CSRC)/kernels_r1.o $(CSRC)/kernels_sq.o $(CSRC)/kernels_r3w.o $(CSRC)/kernels_r3tw.o $(CSRC)/kernels_bluew.o
 
 all: $(LIBDIR)/libfftw3_amd.so
 
@@ -33,6 +33,9 @@ $(CSRC)/kernels_r3r.o: $(CSRC)/kernels_r3r.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/kernels_r2cm.o: $(CSRC)/kernels_r2cm.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/r2crows.hpp $(CSRC)/r2r_epi.hpp $(CSRC)/r2cr_menu.inc
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/kernels_bluew.o: $(CSRC)/kernels_bluew.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass3g.hpp $(CSRC)/pass3b.hpp $(CSRC)/bluew_menu.inc
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(CSRC)/kernels_blue.o: $(CSRC)/kernels_blue.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass3g.hpp $(CSRC)/pass3b.hpp $(CSRC)/blue_menu.inc
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/kernels_r1.o: $(CSRC)/kernels_r1.hip $(HIPCOMMON) $(CSRC)/passrr.hpp $(CSRC)/pass3s.hpp $(CSRC)/pass1r.hpp

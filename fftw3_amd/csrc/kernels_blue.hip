@@ -22,6 +22,11 @@ static void launch_blue(const BlueArgs &ba, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((blue3g_kernel<R1, R2, R3>), grid, dim3(256), lds, st, ba);
 }
 
+/* kernels_bluew.hip: padded lengths 8193 ... 16384, 512 work-items per row */
+int fa_hip_bluew_nb(int need);
+int fa_hip_bluew_has(int nb);
+int fa_launch_bluew(int nb, const BlueArgs &ba, dim3 grid, hipStream_t st);
+
 /* smallest padded length >= need the kernel is built for (0: none) */
 extern "C" int fa_hip_blue_nb(int need) {
     static const int nbs[] = {
@@ -31,7 +36,7 @@ extern "C" int fa_hip_blue_nb(int need) {
     };
     for (size_t i = 0; i < sizeof(nbs) / sizeof(nbs[0]); ++i)
         if (nbs[i] >= need) return nbs[i];
-    return 0;
+    return fa_hip_bluew_nb(need);
 }
 
 /* rows per tile for the padded length nb (0: none) */
@@ -41,7 +46,7 @@ extern "C" int fa_hip_blue_tile(int nb) {
 #include "blue_menu.inc"
 #undef X
     }
-    return 0;
+    return fa_hip_bluew_has(nb) ? 1 : 0;
 }
 
 /* The step (variant FFTW_AMD_K_BLUE: L = nb, aux_n = n, tw_lo = chirp table, tw_hi = kernel table) has no other
@@ -101,5 +106,5 @@ int fa_launch_blue(const fftw_amd_step_desc *d, double *const *bufs, void *const
 #include "blue_menu.inc"
 #undef X
     }
-    return 1;
+    return fa_launch_bluew(d->L, ba, grid, st);
 }

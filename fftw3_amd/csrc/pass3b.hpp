@@ -34,10 +34,10 @@ struct BlueArgs {
 /* stages A, B, C of pass3g.hpp on registers: x (stage-A owners: rows at[], positions aa[] + M i) -> z (stage-C
    owners ct[], cd1[], cd2[]; output c of a butterfly sits in z[.][slot(c)], index cd1 + R1 cd2 + R1 R2 c).
    Ends without a barrier: the caller synchronises before it touches the plane again. */
-template <int R1, int R2, int R3, int QA, int QC>
+template <int R1, int R2, int R3, int QA, int QC, int NT = 256>
 FA_DEV void p3g_core(cplx (*x)[R1], cplx (*z)[R3], double *plane, const cplx *wL, const int Tcur, const int tid,
                      const int *at, const int *aa, int *ct, int *cd1, int *cd2) {
-    typedef P3GGeom<R1, R2, R3> G;
+    typedef P3GGeom<R1, R2, R3, NT> G;
     static_assert(QA == G::QA && QC == G::QC, "geometry");
     constexpr int QB = G::QB;
     constexpr int S1 = G::S1, A2S = G::A2S, SD2 = G::SD2;
@@ -53,7 +53,7 @@ FA_DEV void p3g_core(cplx (*x)[R1], cplx (*z)[R3], double *plane, const cplx *wL
     int ba2[QB], bd1[QB], bt[QB];
 #pragma unroll
     for (int v = 0; v < QB; ++v) {
-        int h = v * 256 + tid;
+        int h = v * NT + tid;
         const int last = Tcur * R1 * R3 - 1;
         h = h < last ? h : last;
         ba2[v] = h % R3;
@@ -90,7 +90,7 @@ FA_DEV void p3g_core(cplx (*x)[R1], cplx (*z)[R3], double *plane, const cplx *wL
     }
 #pragma unroll
     for (int w = 0; w < QC; ++w) {
-        int j = w * 256 + tid;
+        int j = w * NT + tid;
         const int last = Tcur * R1 * R2 - 1;
         j = j < last ? j : last;
         cd1[w] = j % R1;
@@ -122,11 +122,13 @@ FA_DEV void p3g_core(cplx (*x)[R1], cplx (*z)[R3], double *plane, const cplx *wL
     for (int w = 0; w < QC; ++w) RB<R3>::run(z[w]);
 }
 
-template <int R1, int R2, int R3>
-__global__ void __launch_bounds__(256, 2)
+/* NT = 512 (round 3, kernels_bluew.hip): one row of up to 16384 padded points per workgroup of 512 work-items, i.e.
+   lengths n up to 8192 (every prime below 8192) in one kernel */
+template <int R1, int R2, int R3, int NT = 256>
+__global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1)
 blue3g_kernel(const BlueArgs a) {
     extern __shared__ __attribute__((aligned(16))) double plane[];
-    typedef P3GGeom<R1, R2, R3> G;
+    typedef P3GGeom<R1, R2, R3, NT> G;
     constexpr int L = G::L, M = G::M, T = G::T, QA = G::QA, QC = G::QC, KS = R1 * R2;
     const int tid = threadIdx.x;
 
@@ -143,7 +145,7 @@ blue3g_kernel(const BlueArgs a) {
     int at[QA], aa[QA], ct[QC], cd1[QC], cd2[QC];
 #pragma unroll
     for (int u = 0; u < QA; ++u) {
-        int g = u * 256 + tid;
+        int g = u * NT + tid;
         const int last = Tcur * M - 1;
         g = g < last ? g : last;                      /* beyond the tile: redo the last butterfly */
         at[u] = g / M;
@@ -152,16 +154,19 @@ blue3g_kernel(const BlueArgs a) {
 #pragma unroll
         for (int i = 0; i < R1; ++i) {
             const int l = aa[u] + M * i;
-            if (l < n) {
+            if (M * i < (L + 1) / 2 && l < n) {               /* 2n - 1 <= L: the upper half is padding for every n */
                 cplx v = *reinterpret_cast<const cplx *>(row + (i64)l * a.is_l);
                 if (a.flags & FFTW_AMD_F_SWAP_IN) { const double s = v.x; v.x = v.y; v.y = s; }
                 x[u][i] = c_mulc(v, a.chirp[l]);
             } else {
                 x[u][i] = c_make(0.0, 0.0);
             }
+            /* 512 work-items have 256 VGPRs each and no second workgroup on the CU: keep the scheduler from
+               hoisting all R1 element + chirp loads (8 VGPRs a pair) above the first product */
+            if (NT > 256 && (i % 8) == 7) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    p3g_core<R1, R2, R3, QA, QC>(x, z, plane, a.wL, Tcur, tid, at, aa, ct, cd1, cd2);
+    p3g_core<R1, R2, R3, QA, QC, NT>(x, z, plane, a.wL, Tcur, tid, at, aa, ct, cd1, cd2);
 
     /* pointwise product with K, then to the stage-A owners with (re, im) swapped: the second trip through the
        stages is the backward transform */
@@ -171,6 +176,7 @@ blue3g_kernel(const BlueArgs a) {
         for (int c = 0; c < R3; ++c) {
             const int k = cd1[w] + R1 * cd2[w] + KS * c;
             z[w][RB<R3>::slot(c)] = c_mul(z[w][RB<R3>::slot(c)], a.kern[k]);
+            if (NT > 256 && (c % 8) == 7) __builtin_amdgcn_sched_barrier(0);
         }
     __syncthreads();
 #pragma unroll
@@ -194,20 +200,28 @@ blue3g_kernel(const BlueArgs a) {
         for (int i = 0; i < R1; ++i) x[u][i].y = plane[at[u] * L + aa[u] + M * i];
     __syncthreads();
 
-    p3g_core<R1, R2, R3, QA, QC>(x, z, plane, a.wL, Tcur, tid, at, aa, ct, cd1, cd2);
+    p3g_core<R1, R2, R3, QA, QC, NT>(x, z, plane, a.wL, Tcur, tid, at, aa, ct, cd1, cd2);
 
 #pragma unroll
     for (int w = 0; w < QC; ++w) {
         double *row = dst + (i64)ct[w] * a.dos[0];
+        /* an index the compiler cannot identify with the k of the product above: otherwise it keeps the R3 64-bit
+           element offsets computed there alive across the whole second trip (30 spilled register pairs at R3 = 32) */
+        int kb = cd1[w] + R1 * cd2[w];
+        asm volatile("" : "+v"(kb));
 #pragma unroll
         for (int c = 0; c < R3; ++c) {
-            const int k = cd1[w] + R1 * cd2[w] + KS * c;
+            const int k = kb + KS * c;
+            /* 2n - 1 <= L: outputs from (L + 1) / 2 on are never stored, and the last butterfly's share of them is
+               dead code */
+            if (KS * c >= (L + 1) / 2) continue;
             if (k < n) {
                 const cplx v = z[w][RB<R3>::slot(c)];
                 cplx o = c_mulc(c_make(v.y, v.x), a.chirp[k]);
                 if (a.flags & FFTW_AMD_F_SWAP_OUT) { const double s = o.x; o.x = o.y; o.y = s; }
                 *reinterpret_cast<cplx *>(row + (i64)k * a.os_l) = o;
             }
+            if (NT > 256 && (c % 8) == 7) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

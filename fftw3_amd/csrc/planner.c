@@ -944,7 +944,7 @@ static int emit_bluestein_rows(plan *p, const fa_axis *ax) {
     sdim d[FA_MAXLOOPS];
     fftw_amd_step_desc *s;
     if (getenv("FFTW_AMD_NO_TUNED") || getenv("FFTW_AMD_NO_3S") || getenv("FFTW_AMD_NO_BLUE_ROWS")) return 0;
-    if (ax->n < 2 || need > 8192 || ax->nloops == 0) return 0;
+    if (ax->n < 2 || need > 16384 || ax->nloops == 0) return 0;
     nb = fa_hip_blue_nb((int)need);
     if (nb <= 0 || (double)nb > 1.35 * (double)need) return 0;
     if (!long_rows_ok(p, ax)) return 0;

@@ -314,9 +314,10 @@ def test_mixed_and_three_stage_real_rows(L, r1, r2, r3):
 
 def blue_menu():
     out = []
-    with open(os.path.join(ROOT, "fftw3_amd", "csrc", "blue_menu.inc")) as f:
-        for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read()):
-            out.append(int(m.group(1)))
+    for name in ("blue_menu.inc", "bluew_menu.inc"):          # 256 / 512 work-items per workgroup
+        with open(os.path.join(ROOT, "fftw3_amd", "csrc", name)) as f:
+            for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+)\)", f.read()):
+                out.append(int(m.group(1)))
     return out
 
 
@@ -340,7 +341,7 @@ def _largest_fitting_hard_length(nb, lo):
 
 @pytest.mark.parametrize("idx", list(range(len(BLUE))), ids=[str(v) for v in BLUE])
 def test_bluestein_rows_kernel(idx, monkeypatch):
-    """every padded length of blue_menu.inc: rows of the largest length that needs it, forward out of place with a
+    """every padded length of blue_menu.inc / bluew_menu.inc: rows of the largest length that needs it, forward out of place with a
     ragged last tile and backward in place, against the oracle; the step-by-step plan (FFTW_AMD_NO_BLUE_ROWS) agrees"""
     import torch
     nb = BLUE[idx]

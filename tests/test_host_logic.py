@@ -502,7 +502,11 @@ def test_one_trip_rows_plans():
     assert "pass-2145/bluestein-rows n=1031" in one(1031, 8).sprint()
     assert "bluestein-rows" not in one(1031, 8, fa.ESTIMATE | fa.UNALIGNED).sprint()
     assert "bluestein-rows" not in one(37, 64).sprint()                        # the ladder would pad 7 x
-    for n, b in ((5000, 3), (16384, 2), (1031, 5), (23, 300), (1018, 2)):
+    # padded lengths above 8192: one row per workgroup of 512 work-items (kernels_bluew.hip), every prime below 8192
+    assert "pass-16384/bluestein-rows n=8191" in one(8191, 4).sprint() and len(one(8191, 4).steps()) == 1
+    assert "pass-8640/bluestein-rows n=4099" in one(4099, 4).sprint()
+    assert "bluestein-rows" not in one(8209, 4).sprint()
+    for n, b in ((5000, 3), (16384, 2), (1031, 5), (23, 300), (1018, 2), (4099, 2), (8191, 1)):
         for sign in (-1, 1):
             e, p = _c2c(n, b, sign)
             assert e < TOL, (n, p.sprint())
