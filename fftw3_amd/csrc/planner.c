@@ -971,6 +971,23 @@ static int emit_bluestein_rows(plan *p, const fa_axis *ax) {
     return 1;
 }
 
+/* cost of a pass of L points on the 512-item strided / transposed three-stage kernels (r3tw_menu.inc), in ms per
+   GiB moved like split_costs.inc: last = 0 first pass (columns), 1 last pass (rows in, transposed store, twiddle on
+   the input).  Measured with tools/perf/perf_pow2_two_trip.py (profiles/r03_two_trip_wide.txt), taking the two
+   2048-point passes as equal; 0: no such kernel */
+static double wide_pass_cost(i64 L, int last) {
+    static const struct { int L; double first, last; } c[] = {
+        { 2048, 0.239, 0.239 }, { 2000, 0.247, 0.247 }, { 1920, 0.185, 0.207 }, { 1600, 0.265, 0.265 },
+        { 1536, 0.274, 0.290 }, { 1440, 0.339, 0.339 }, { 1280, 0.227, 0.198 }, { 1200, 0.300, 0.300 },
+        { 1080, 0.269, 0.298 },
+    };
+    size_t i;
+    if (L <= 1024 || fa_hip_r3t_tile((int)L) < 8) return 0.0;
+    for (i = 0; i < sizeof(c) / sizeof(c[0]); ++i)
+        if (c[i].L == L) return last ? c[i].last : c[i].first;
+    return 0.0;
+}
+
 static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
     fa_axis ax = *ax_in;
     i64 lens[FA_MAXPASS];
@@ -1058,11 +1075,22 @@ static void fa_emit_axis(plan *p, const fa_axis *ax_in) {
         }
         for (L1 = 2048; L1 > 1024; --L1) {
             i64 L2 = ax.n / L1;
-            double c2;
-            if (ax.n % L1 || fa_hip_r3t_tile((int)L1) <= 0 || L2 > 1024 || L2 < 96 || !has_register_kernel(L2)) continue;
-            c2 = L2 == 1024 ? 0.18 : (L2 == 1000 ? 0.20 : split_cost_measured(L2, 2));
+            double c1, c2;
+            if (ax.n % L1 || fa_hip_r3t_tile((int)L1) <= 0 || L2 < 96) continue;
+            /* round 3: the 512-item kernels of r3tw_menu.inc (8 ... 15 sequences per tile) are cheaper first passes
+               than the narrow tiles, and serve as LAST pass too (rows in, transposed store, twiddle on the input):
+               both lengths above 1024, e.g. 2^22 = 2048 x 2048 in 3.8 instead of 5.4 ms per 4 GiB */
+            c1 = wide_pass_cost(L1, 0);
+            if (c1 <= 0.0) c1 = 0.34;
+            if (L2 > 1024) {
+                c2 = L2 <= 2048 ? wide_pass_cost(L2, 1) : 0.0;
+                if (c2 <= 0.0 || wide_pass_cost(L1, 0) <= 0.0) continue;
+            } else {
+                if (!has_register_kernel(L2)) continue;
+                c2 = L2 == 1024 ? 0.18 : (L2 == 1000 ? 0.20 : split_cost_measured(L2, 2));
+            }
             if (c2 <= 0.0) continue;                  /* no measurement for that partner: do not guess */
-            if (0.34 + c2 < best2) { best2 = 0.34 + c2; bestL1 = L1; }
+            if (c1 + c2 < best2) { best2 = c1 + c2; bestL1 = L1; }
         }
         if (bestL1 && best2 < 0.95 * est3) { k = 2; lens[0] = bestL1; lens[1] = ax.n / bestL1; }
     }

@@ -50,6 +50,27 @@ def test_c2c_1d_matches_oracle(torch_dev, n):
     assert aerror(y, oracle_dft(x, (n,), 2).reshape(2, n)) < TOL
 
 
+@pytest.mark.parametrize("n", [1 << 22, 1920 * 2048, 2000 * 2000, 1080 * 1920, 2048 * 1280])
+def test_two_trips_with_both_lengths_above_1024(torch_dev, n):
+    """n = L1 x L2 with both lengths in 1025 ... 2048: two trips through the 512-item strided / transposed kernels
+    (first pass down the columns, last pass rows in / transposed store with the twiddle on its input), where round 2
+    took three; a batch that is not a multiple of anything, forward out of place and backward in place"""
+    torch, dev = torch_dev
+    rng = np.random.default_rng(n)
+    b = 3
+    x = crand(rng, b, n)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.zeros_like(xd)
+    p = fa.plan_many_dft(1, [n], b, xd, None, 1, n, yd, None, 1, n, fa.FORWARD)
+    lens = [s.L for s in p.steps()]
+    assert len(lens) == 2 and min(lens) > 1024 and lens[0] * lens[1] == n, p.sprint()
+    p.execute()
+    torch.cuda.synchronize()
+    assert aerror(yd.cpu().numpy(), oracle_dft(x, (n,), b).reshape(b, n)) < TOL
+    y = gpu_c2c(torch_dev, x, (n,), b, +1, inplace=True)
+    assert aerror(y, oracle_dft(x, (n,), b, +1).reshape(b, n)) < TOL
+
+
 def test_sweep_1_to_100_and_pow2(torch_dev):
     """the reference's size sweep (fftw/tests/check.pl:126-173), forward and backward"""
     rng = np.random.default_rng(7)
@@ -1098,9 +1119,9 @@ def test_chunk_lanes(torch_dev, monkeypatch, lanes):
         torch.cuda.synchronize()
         assert aerror(z2.cpu().numpy(), oracle_dft(x2, (n,), b).reshape(b, n)) < TOL
         del xd, zd, z2, yd
-        # three passes (2^22), r2c (passes + untangle), mixed radix
+        # three passes (2^23), r2c (passes + untangle), mixed radix
         fa.set_chunk_bytes(64 << 20)
-        n, b = 1 << 22, 3
+        n, b = 1 << 23, 3
         x = crand(rng, b, n)
         y = gpu_c2c(torch_dev, x, (n,), b)
         assert aerror(y, oracle_dft(x, (n,), b).reshape(b, n)) < TOL

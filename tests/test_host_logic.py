@@ -445,7 +445,7 @@ def test_split_models_keep_the_factorisation_exact_and_prefer_measured_winners()
     the product of the pass lengths is n, every length has a register kernel; spot checks of picks the
     sweeps established (profiles/r02_*_split_samples.jsonl)"""
     x = np.zeros(4, dtype=complex)
-    for n in (1 << 14, 1 << 16, 1 << 17, 1 << 19, 1 << 20, 1 << 21, 10 ** 4, 10 ** 5, 10 ** 6, 60060, 518400,
+    for n in (1 << 14, 1 << 16, 1 << 17, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 4 * 10 ** 6, 10 ** 4, 10 ** 5, 10 ** 6, 60060, 518400,
               15375360, 10 ** 7, 6 ** 9, 14817600, 1080 * 1024, 2000 * 1000):
         p = fa.plan_many_dft(1, [n], 64, x, None, 1, n, x.copy(), None, 1, n, fa.FORWARD)
         lens = _pass_lengths(p)
@@ -455,6 +455,8 @@ def test_split_models_keep_the_factorisation_exact_and_prefer_measured_winners()
     assert lens(1 << 16) == [128, 512]                    # not 256 x 256: the 256-point kernel is the slow one
     assert lens(1 << 20) == [1024, 1024]
     assert lens(1 << 21) == [2048, 1024]                  # two trips through the narrow-tile 2048-point kernel
+    assert lens(1 << 22) == [2048, 2048]                  # round 3: both passes on the 512-item kernels (8 per tile)
+    assert lens(1920 * 2048) == [1920, 2048] and len(lens(1 << 23)) == 3
     three = lens(15375360)
     assert len(three) == 3 and three[0] % 8 == 0          # first length on the 128-byte grid
     # a strided axis of 1025 ... 2048 points runs in one trip (the 1080 of a 1080 x 1920 image)
