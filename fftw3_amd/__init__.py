@@ -57,6 +57,7 @@ F_MUL_TABLE, F_MUL_CONJ, F_PERM_SRC, F_PERM_DST, F_CONJ_OUT, F_TW_IN = 16, 32, 6
 F_R2C_ROWS = 1024
 F_C2R_ROWS = 2048
 F_LO_DFT = 1 << 14
+F_REAL_DEC = 1 << 15
 
 
 class StepDesc(C.Structure):

@@ -185,12 +185,16 @@ static plan *finish_locked(plan *p, double *ri, double *ii, double *ro, double *
             static const size_t chunks[] = { (size_t)64 << 20, (size_t)128 << 20, (size_t)256 << 20, (size_t)1 << 30, (size_t)4 << 30 };
             fa_cfg best = p->cfg, c;
             double best_ms = -1.0;
-            int ci, pi, li, st, lf, nl = (p->flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1;
+            int ci, pi, li, st, lf, rd, nl = (p->flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1;
+            /* r2c problems: also the plan decimated over the real data (cfg.real_dec), with the default chunking only */
+            const int nrd = (p->type == FA_R2C) ? 2 : 1;
+            for (rd = 0; rd < nrd; ++rd)
             for (ci = 0; ci < 5; ++ci)
                 for (pi = 0; pi < 2; ++pi)
                     for (li = 0; li < nl; ++li)
                         for (st = 0; st < nl; ++st)
                         for (lf = 0; lf < 2; ++lf) {
+                            if (rd && (ci != 1 || pi || li || st || lf)) continue;
                             plan *q;
                             double t0, dt;
                             c = p->cfg;
@@ -200,6 +204,7 @@ static plan *finish_locked(plan *p, double *ri, double *ii, double *ro, double *
                             c.lmax_multi = li ? 512 : 1024;
                             c.small_tiles = st;
                             c.long_first = lf;
+                            c.real_dec = rd;
                             q = clone_problem(p, c);
                             if (!q) continue;
                             /* the builder looks at the arrays (alignment, aliasing) */
@@ -742,7 +747,7 @@ void fftw_cleanup_threads(void) {}
 void fftw_make_planner_thread_safe(void) {}
 
 /* ---- wisdom: text records "(key) chunk pipeline lmax bits ms", one per problem
-   (bits: 1 = small_tiles, 2 = long_first, 4 | 8 = chunk lanes - 1) */
+   (bits: 1 = small_tiles, 2 = long_first, 4 | 8 = chunk lanes - 1, 16 = real_dec) */
 void fftw_forget_wisdom(void) {
     pthread_mutex_lock(&g_planner_lock);
     while (g_wisdom) { wis_entry *n = g_wisdom->next; free(g_wisdom); g_wisdom = n; }
@@ -761,7 +766,7 @@ char *fftw_export_wisdom_to_string(void) {
     len += (size_t)snprintf(s + len, cap - len, "(fftw3_amd_wisdom-1\n");
     for (w = g_wisdom; w; w = w->next)
         len += (size_t)snprintf(s + len, cap - len, "  (%s) %zu %d %d %d %.6f\n", w->key, w->cfg.chunk_bytes,
-                                w->cfg.pipeline, w->cfg.lmax_multi, (w->cfg.small_tiles ? 1 : 0) | (w->cfg.long_first ? 2 : 0) | (((w->cfg.lanes > 1 ? w->cfg.lanes - 1 : 0) & 3) << 2), w->ms);
+                                w->cfg.pipeline, w->cfg.lmax_multi, (w->cfg.small_tiles ? 1 : 0) | (w->cfg.long_first ? 2 : 0) | (((w->cfg.lanes > 1 ? w->cfg.lanes - 1 : 0) & 3) << 2) | (w->cfg.real_dec ? 16 : 0), w->ms);
     snprintf(s + len, cap - len, ")\n");
     pthread_mutex_unlock(&g_planner_lock);
     return s;
@@ -809,7 +814,7 @@ int fftw_import_wisdom_from_string(const char *input) {
         w = (wis_entry *)calloc(1, sizeof(*w));
         if (!w) { ok = 0; break; }
         snprintf(w->key, sizeof(w->key), "%s", key);
-        w->cfg.chunk_bytes = chunk; w->cfg.pipeline = pipe != 0; w->cfg.lmax_multi = lmax; w->cfg.small_tiles = (small & 1) != 0; w->cfg.long_first = (small & 2) != 0; w->cfg.lanes = 1 + ((small >> 2) & 3);
+        w->cfg.chunk_bytes = chunk; w->cfg.pipeline = pipe != 0; w->cfg.lmax_multi = lmax; w->cfg.small_tiles = (small & 1) != 0; w->cfg.long_first = (small & 2) != 0; w->cfg.lanes = 1 + ((small >> 2) & 3); w->cfg.real_dec = (small & 16) != 0;
         w->ms = ms;
         w->next = staged;
         staged = w;

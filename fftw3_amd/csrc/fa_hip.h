@@ -16,6 +16,7 @@ int   fa_hip_device_count(void);
 /* sequences per tile of the two-stage register kernel for length L, 0 if there is none */
 int   fa_hip_rr_tile(int L);
 int   fa_hip_r3t_tile(int L);  /* sequences per tile of the strided three-stage kernel, 0: none */
+int   fa_hip_r3tw_rdec(int L); /* 1: the length has the real-decimated rows form (FFTW_AMD_F_REAL_DEC) */
 int   fa_hip_r2c_rows_tile(int L);  /* rows per tile of the fused real-rows kernel for half length L, 0: none */
 int   fa_hip_r2c_rows1_tile(int L);  /* ... of the one-stage real-rows kernel (dense rows, half length 2 ... 32), 0: none */
 int   fa_hip_r2c_rows2m_tile(int L); /* ... of the mixed-radix two-stage lengths (plain r2c / c2r, half length 72 ... 648), 0: none */

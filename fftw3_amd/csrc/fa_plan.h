@@ -65,6 +65,9 @@ typedef struct {
     int long_first;       /* multi-pass splits run the longest sub-transform first */
     int lanes;            /* chunk lanes: chunk c runs all its steps on stream c % lanes, scratch slot c % lanes */
     i64 tile_elems;       /* FFTW_AMD_TILE_ELEMS: tile size of the generic LDS kernel, 0 = default (not tuned) */
+    int real_dec;         /* FFTW_AMD_REAL_DEC: long r2c transforms decimated over the real data (two trips on the 512-item
+                             kernels, emit_r2c_decimated) instead of the half- / quarter-length plans; off by default
+                             (measured a few % behind them except near n = 2^20), a FFTW_MEASURE candidate */
 } fa_cfg;
 
 typedef struct {

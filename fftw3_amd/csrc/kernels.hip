@@ -1318,6 +1318,12 @@ static int launch_pass(const fftw_amd_step_desc *d, double *const *bufs, void *c
                        i64 cs, i64 cn, hipStream_t st) {
     PassArgs pa;
     if (d->flags & (FFTW_AMD_F_R2C_ROWS | FFTW_AMD_F_C2R_ROWS)) return fa_launch_r2crows(d, bufs, tables, cs, cn, st);
+    if (d->flags & FFTW_AMD_F_REAL_DEC) {
+        /* the last trip of a two-trip r2c: one executor (kernels_r3tw.hip), planned only where it applies */
+        if (fa_launch_pass3tw(d, bufs, tables, cs, cn, st) == 0) return 0;
+        fprintf(stderr, "fftw3_amd: internal error: real-decimated rows step with an unsupported layout\n");
+        abort();
+    }
     if (d->variant == FFTW_AMD_K_P1024 && launch_p1024(d, bufs, tables, cs, cn, st) == 0) return 0;
     if (d->variant == FFTW_AMD_K_BLUE) return fa_launch_blue(d, bufs, tables, cs, cn, st);
     if (d->variant == FFTW_AMD_K_R1 && fa_launch_pass1r(d, bufs, tables, cs, cn, st) == 0) return 0;

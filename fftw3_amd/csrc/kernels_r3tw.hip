@@ -11,7 +11,7 @@
 #include "pass3s.hpp"
 #include "pass3g.hpp"
 
-template <int R1, int R2, int R3, bool IN_T, int TW>
+template <int R1, int R2, int R3, bool IN_T, int TW, int RD = 0>
 static void launch_3tw_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
     static std::atomic<unsigned> attr_done{0};
     typedef P3TGeom<R1, R2, R3, 512> G;
@@ -19,11 +19,11 @@ static void launch_3tw_variant(const P1024Args &pa, dim3 grid, hipStream_t st) {
     static_assert(G::lds_doubles * sizeof(double) <= 160 * 1024, "wide strided menu entry exceeds the LDS");
     const size_t lds = G::lds_doubles * sizeof(double);
     if (fa_attr_needed(attr_done)) {
-        FA_CHECK(hipFuncSetAttribute((const void *)pass3t_kernel<R1, R2, R3, IN_T, TW, 512>,
+        FA_CHECK(hipFuncSetAttribute((const void *)pass3t_kernel<R1, R2, R3, IN_T, TW, 512, RD>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         fa_attr_set(attr_done);
     }
-    hipLaunchKernelGGL((pass3t_kernel<R1, R2, R3, IN_T, TW, 512>), grid, dim3(512), lds, st, pa);
+    hipLaunchKernelGGL((pass3t_kernel<R1, R2, R3, IN_T, TW, 512, RD>), grid, dim3(512), lds, st, pa);
 }
 
 template <int R1, int R2, int R3>
@@ -40,6 +40,9 @@ static int dispatch_3tw(const P1024Args &pa, dim3 grid, hipStream_t st, bool in_
     return 1;
 }
 
+/* 1 = the length has the real-decimated rows form (FFTW_AMD_F_REAL_DEC: last trip of a two-trip r2c) */
+extern "C" int fa_hip_r3tw_rdec(int L) { return L == 2048; }
+
 /* sequences per tile of the 512-item strided kernel for length L (0: none) */
 extern "C" int fa_hip_r3tw_tile(int L) {
     switch (L) {
@@ -50,14 +53,20 @@ extern "C" int fa_hip_r3tw_tile(int L) {
     return 0;
 }
 
+static inline dim3 grid_of(i64 nblocks) { return dim3((unsigned)nblocks, 1, 1); }
+
 int fa_launch_pass3tw(const fftw_amd_step_desc *d, double *const *bufs, void *const *tables,
                       i64 cs, i64 cn, hipStream_t st) {
     P1024Args pa;
     int bd = d->batch_dim;
     i64 sbase = d->src_base, dbase = d->dst_base;
     const int T = fa_hip_r3tw_tile(d->L);
+    const bool rdec = (d->flags & FFTW_AMD_F_REAL_DEC) != 0;
     if (T <= 0 || d->tile != T || d->src_im != 1 || d->dst_im != 1 || d->tile_lo_n > 1 ||
         (d->flags & (FFTW_AMD_F_REAL_IN | FFTW_AMD_F_REAL_OUT | FFTW_AMD_F_CONJ_OUT | FFTW_AMD_F_LO_DFT)))
+        return 1;
+    if (rdec && (!fa_hip_r3tw_rdec(d->L) || (d->flags & (FFTW_AMD_F_SWAP_IN | FFTW_AMD_F_SWAP_OUT)) || !(d->flags & FFTW_AMD_F_TW_IN) ||
+                 d->tw_n == 0 || d->dim_tw[0] != 1 || d->dim_n[0] < 2 || d->batch_dim == 0))
         return 1;
     for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) {
         pa.dn[i] = (i < d->ndims) ? d->dim_n[i] : 1;
@@ -91,6 +100,13 @@ int fa_launch_pass3tw(const fftw_amd_step_desc *d, double *const *bufs, void *co
     if (nblocks <= 0) return 0;
     if (nblocks > 0x7fffffffLL) return 1;
     if (pa.dn[0] * 4 < T) return 1;              /* a mostly empty tile: the LDS kernel */
+    if (rdec) {
+        bool in_t = pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l);
+        bool out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);
+        if (in_t || !out_t || d->L != 2048) return 1;
+        launch_3tw_variant<8, 16, 16, false, 2, 1>(pa, grid_of(nblocks), st);
+        return 0;
+    }
     dim3 grid((unsigned)nblocks, 1, 1);
     bool in_t = pa.dn[0] > 1 && iabs64(pa.dis[0]) <= iabs64(pa.is_l);
     bool out_t = pa.dn[0] > 1 && iabs64(pa.dos[0]) <= iabs64(pa.os_l);

@@ -326,9 +326,21 @@ template <int R1, int R2, int R3, int NT = 256> struct P3TGeom {
     static constexpr int lds_doubles = (E1 > (E2C > E2R ? E2C : E2R) ? E1 : (E2C > E2R ? E2C : E2R)) + 16;
 };
 
-template <int R1, int R2, int R3, bool IN_T, int HAS_TW, int NT = 256>
+/* RD = 1 (round 3; rows form with the twiddle on the input only, FFTW_AMD_F_REAL_DEC): the LAST trip of a two-trip
+   r2c transform of n = L1 x L real points.  Trip 1 was the plain complex pass of length L1 down the columns of the
+   real array read as [L1][L / 2] complex pairs: Z[k1][c] = A[k1][2c] + i A[k1][2c + 1], A[k1][j2] the length-L1 real
+   DFT of column j2.  This trip takes the rows k1 = 0 ... L1 / 2 (the tile dim, dn[0] = L1 / 2 + 1): it separates
+        A[k1][2c]     = (Z[k1][c] + conj Z[L1 - k1][c]) / 2
+        A[k1][2c + 1] = (Z[k1][c] - conj Z[L1 - k1][c]) / (2 i)
+   while loading (two rows of L / 2 pairs: the mirror lives on the LOAD side, where it is only an address), applies
+   the twiddle w_n^(k1 j2), transforms the row (length L) and stores X[k1 + L1 k2] for k2 < L / 2 in place and the
+   conjugate of the others at n - (k1 + L1 k2) = (L1 - k1) + L1 (L - 1 - k2) -- the half spectrum 0 ... n / 2, every
+   store a run of T consecutive outputs.  Reference counterpart: the rdft2 Cooley-Tukey node over real codelets,
+   hc2cf / r2cf (fftw/rdft_scalar/r2cf/hc2cfdft_*.c under ct_hc2c_direct_apply, fftw/fftw_api.c:5831). */
+template <int R1, int R2, int R3, bool IN_T, int HAS_TW, int NT = 256, int RD = 0>
 __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1)
 pass3t_kernel(const P1024Args a) {
+    static_assert(RD == 0 || (!IN_T && HAS_TW == 2 && (R2 * R3) % 2 == 0 && R3 % 2 == 0), "real-decimated rows: rows form, twiddle on the input");
     extern __shared__ __attribute__((aligned(16))) double plane[];
     typedef P3TGeom<R1, R2, R3, NT> G;
     constexpr int M = G::M, T = G::T, QA = G::QA, QB = G::QB, QC = G::QC;
@@ -353,6 +365,23 @@ pass3t_kernel(const P1024Args a) {
         aa[u] = IN_T ? g / T : g % M;
         t = t < Tcur - 1 ? t : Tcur - 1;              /* sequences past the end: redo the last one */
         at[u] = t;
+        if constexpr (RD == 1) {
+            /* element l = aa + M i of row k1 is A[k1][l]: pair c = l / 2 of the rows k1 and L1 - k1 of Z */
+            const i64 k1 = t0 + t, L1 = 2 * (a.dn[0] - 1);
+            const i64 km = k1 ? L1 - k1 : 0;
+            const double *r1 = a.src + soff + k1 * a.dis[0] + (i64)(aa[u] >> 1) * a.is_l;
+            const double *r2 = a.src + soff + km * a.dis[0] + (i64)(aa[u] >> 1) * a.is_l;
+            const i64 step = (i64)(M / 2) * a.is_l;
+            const bool odd = (aa[u] & 1) != 0;
+#pragma unroll
+            for (int i = 0; i < R1; ++i) {
+                const cplx v1 = *reinterpret_cast<const cplx *>(r1 + i * step);
+                const cplx v2 = *reinterpret_cast<const cplx *>(r2 + i * step);
+                x[u][i] = odd ? c_make(0.5 * (v1.y + v2.y), 0.5 * (v2.x - v1.x))
+                              : c_make(0.5 * (v1.x + v2.x), 0.5 * (v1.y - v2.y));
+            }
+            continue;
+        }
         const double *p = src + (i64)aa[u] * a.is_l + (i64)t * a.dis[0];
         const i64 step = (i64)M * a.is_l;
         ld_run<R1>(x[u], p, step, (a.flags & FFTW_AMD_F_NT_IN) != 0);
@@ -479,6 +508,34 @@ pass3t_kernel(const P1024Args a) {
         }
         double *p = dst + (i64)kb * a.os_l + (i64)tc * a.dos[0];
         const i64 step = (i64)(R1 * R2) * a.os_l;
+        if constexpr (RD == 1) {
+            /* k2 = kb + R1 R2 c: the first R3 / 2 outputs are below L / 2 and stored in place, the others are the
+               conjugates of outputs n - k of the rows this trip does not compute */
+            const i64 k1 = t0 + tc, L1 = 2 * (a.dn[0] - 1);
+            const bool edge = k1 == 0 || 2 * k1 == L1;          /* rows that are their own mirror */
+            double *pm = a.dst + doff + (L1 - k1) * a.dos[0] + (i64)(G::L - 1 - kb) * a.os_l;
+            /* one branch around all the stores, not one per store (spilled VGPRs in the 512-item kernels) */
+            auto stores = [&](auto ntc) {
+                constexpr bool NTS = decltype(ntc)::value;
+#pragma unroll
+                for (int c = 0; c < R3 / 2; ++c) {
+                    cplx v = z[w][RB<R3>::slot(c)];
+                    if (c == 0 && k1 == 0 && kb == 0) v.y = 0.0;                        /* X[0] */
+                    st_cplx<NTS>(p + c * step, v);
+                }
+                if (!edge) {
+#pragma unroll
+                    for (int c = R3 / 2; c < R3; ++c) {
+                        const cplx v = z[w][RB<R3>::slot(c)];
+                        st_cplx<NTS>(pm - c * step, c_make(v.x, -v.y));
+                    }
+                } else if (k1 == 0 && kb == 0) {
+                    st_cplx<NTS>(p + (R3 / 2) * step, c_make(z[w][RB<R3>::slot(R3 / 2)].x, 0.0));   /* X[n / 2] */
+                }
+            };
+            if (a.flags & FFTW_AMD_F_NT_OUT) stores(std::true_type{}); else stores(std::false_type{});
+            continue;
+        }
         if constexpr (NT > 256) {
             /* one branch around the run of stores, not one per store (spilled VGPRs in the 512-item kernels) */
             if (a.flags & FFTW_AMD_F_NT_OUT) {

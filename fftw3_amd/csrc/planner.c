@@ -53,6 +53,7 @@ fa_cfg fa_default_cfg(void) {
     c.small_tiles = 1;
     c.long_first = 0;
     c.tile_elems = 0;
+    c.real_dec = 0;
     c.lanes = 2;
     e = getenv("FFTW_AMD_CHUNK_BYTES");
     if (e && atoll(e) > 0) c.chunk_bytes = (size_t)atoll(e);
@@ -66,6 +67,8 @@ fa_cfg fa_default_cfg(void) {
     if (e) c.pipeline = atoi(e);
     e = getenv("FFTW_AMD_LMAX_MULTI");
     if (e && atoll(e) >= 16) c.lmax_multi = (int)atoll(e);
+    e = getenv("FFTW_AMD_REAL_DEC");
+    if (e) c.real_dec = atoi(e) != 0;
     e = getenv("FFTW_AMD_LANES");
     if (e && atoi(e) >= 1 && atoi(e) <= FA_MAXLANES) c.lanes = atoi(e);
     return c;
@@ -1351,6 +1354,14 @@ static int axis_pass_count(const plan *p, i64 n) {
     return k ? k : 99;
 }
 
+/* The quarter-length transforms of the radix-4 real plans run on PAIRS of interleaved vectors (a two-level tile dim),
+   which only the power-of-two two-stage kernels and the 1024-point kernel take; a multi-pass m with another factor
+   would put a pass on the runtime-radix LDS kernel (3 932 160 = 4 x 960 x 1024: 7.9 ms per 4 GiB where the half-length
+   plan takes 4.3, profiles/r03_r2c_two_trip.txt).  One-pass lengths keep the old rule. */
+static int radix4_passes_have_kernels(const plan *p, i64 m) {
+    return axis_pass_count(p, m) <= 1 || (m & (m - 1)) == 0;
+}
+
 /* passes of the half-length complex transform of an r2c / c2r axis: its rows are contiguous, so a length with
    a three-stage rows kernel (up to 8192) is one pass */
 static int half_axis_pass_count(const plan *p, i64 n) {
@@ -1469,6 +1480,90 @@ static void r2r_fuse_tables(plan *p, fftw_amd_step_desc *s, i64 nl, int mode) {
     }
 }
 
+/* A long real transform in TWO trips (round 3): n = L1 x L2 real points, decimated over the real data itself
+   instead of packed into a half-length complex transform plus an untangle trip.
+     trip 1   the plain complex pass of length L1 down the columns of the input read as [L1][L2 / 2] pairs
+              (x[j1 L2 + 2c], x[j1 L2 + 2c + 1]) -> Z[k1][c] in scratch: the real DFTs of two columns in one
+     trip 2   rows k1 = 0 ... L1 / 2: separate the two columns while loading (rows k1 and L1 - k1 of Z), twiddle,
+              DFT of length L2 along the row, store X[k1 + L1 k2] and, conjugated, X[n - (k1 + L1 k2)]
+              (FFTW_AMD_F_REAL_DEC, pass3t_kernel RD = 1)
+   Both trips move n / 2 complex numbers in and out: 2 x the algorithmic bytes where the half-length plans need
+   3 x (two passes + untangle).  2^22 = 2048 x 2048 (BASELINE cfg3), 2^21 = 1024 x 2048.
+   MEASURED (tools/perf/perf_r2c_two_trip.py, profiles/r03_r2c_two_trip.txt): with the 512-item kernels (one
+   workgroup per CU, ~4.5 TB/s per trip with two chunk lanes) the two trips only TIE with the three trips of the
+   256-item kernels, whose scratch chunks stay in the Infinity Cache (2^22: 4.58 against 4.11 ms per 4 GiB; 2^20:
+   3.98 against 4.10) -- so the plan is off under FFTW_ESTIMATE (cfg.real_dec, FFTW_AMD_REAL_DEC=1) and a candidate
+   of the FFTW_MEASURE search for r2c problems.  Reference counterpart: the
+   rdft2 Cooley-Tukey plan over real-data codelets (ct_hc2c_direct_apply, fftw/fftw_api.c:5831, with
+   fftw/rdft_scalar/r2cf/hc2cfdft_*.c).  The last step has no fallback executor, so everything it needs is settled
+   here (aligned interleaved arrays, even strides).  1 = emitted. */
+static int emit_r2c_decimated(plan *p, i64 nl, const fa_axis *axp, fa_loc in, fa_loc out) {
+    fa_axis ax = *axp, c_ax, lay;
+    const i64 L2 = 2048;
+    i64 L1, h = nl / 2, zts, lts[FA_MAXLOOPS + 1], total;
+    int zbuf, j, nd, cloop, n0 = p->nsteps;
+    double flops0 = p->est_flops;
+    fa_loc z;
+    sdim d[FA_MAXLOOPS + 1];
+    fftw_amd_step_desc *s;
+    if (!p->cfg.real_dec || getenv("FFTW_AMD_NO_TUNED") || getenv("FFTW_AMD_NO_NARROW") ||
+        (p->flags & FFTW_UNALIGNED) || p->cfg.lmax_multi < 1024)
+        return 0;
+    if (nl % L2 || !fa_hip_r3tw_rdec((int)L2) || fa_hip_r3t_tile((int)L2) < 8) return 0;
+    L1 = nl / L2;
+    if (L1 % 2 || L1 < 256) return 0;
+    /* trip 1 must be ONE strided pass: a register kernel of that length with 128-byte segments */
+    if (!((L1 <= 1024 && has_register_kernel(L1)) || (L1 <= 2048 && fa_hip_r3t_tile((int)L1) >= 8))) return 0;
+    if (ax.nloops >= FA_MAXLOOPS || in.im != 0 || out.im != 1) return 0;
+    if ((in.base % 2) || (out.base % 2) || ((size_t)p->ri % 16) || ((size_t)p->ro % 16)) return 0;
+    for (j = 0; j < ax.nloops; ++j)
+        if ((ax.loops[j].is % 2) || (ax.loops[j].os % 2)) return 0;
+
+    lay = ax;
+    lay.is = 1;
+    total = scratch_layout(&lay, h, &zts, lts);
+    zbuf = buf_acquire(p, total);
+    z.buf = zbuf; z.base = 0; z.im = 1;
+
+    c_ax = ax;
+    cloop = c_ax.nloops++;
+    c_ax.loops[cloop].n = L2 / 2;
+    c_ax.loops[cloop].is = 2;
+    c_ax.loops[cloop].os = zts;
+    for (j = 0; j < ax.nloops; ++j) c_ax.loops[j].os = lts[j];
+    c_ax.n = L1;
+    c_ax.is = L2;                      /* L2 / 2 pairs of two doubles */
+    c_ax.os = (L2 / 2) * zts;
+    c_ax.src = in;
+    c_ax.src.im = 1;                   /* odd sample = imaginary part */
+    c_ax.dst = z;
+    c_ax.dense = 0;
+    c_ax.flags_in = c_ax.flags_out = 0;
+    fa_emit_axis(p, &c_ax);
+    if (p->failed || p->nsteps != n0 + 1) goto undo;
+
+    nd = 0;
+    d[nd].n = L1 / 2 + 1; d[nd].is = (L2 / 2) * zts; d[nd].os = 2; d[nd].tw = 1; d[nd].is_batch = 0; ++nd;
+    for (j = 0; j < ax.nloops; ++j) {
+        d[nd].n = ax.loops[j].n; d[nd].is = lts[j]; d[nd].os = ax.loops[j].os;
+        d[nd].tw = 0; d[nd].is_batch = (j == ax.batch_loop); ++nd;
+    }
+    emit_pass(p, z, out, L2, zts, 2 * L1, d, nd, nl, FFTW_AMD_F_TW_IN | FFTW_AMD_F_REAL_DEC);
+    if (p->failed) goto undo;
+    s = &p->steps[p->nsteps - 1];
+    if (s->variant != FFTW_AMD_K_R3 || s->tile != fa_hip_r3t_tile((int)L2) || s->tile_lo_n != 1 ||
+        s->dim_n[0] != L1 / 2 + 1 || s->dim_tw[0] != 1 || s->batch_dim == 0)
+        goto undo;
+    buf_release(p, zbuf);
+    return 1;
+undo:
+    if (p->failed) return 1;
+    p->nsteps = n0;
+    p->est_flops = flops0;
+    buf_release(p, zbuf);
+    return 0;
+}
+
 /* epi: 0 = store the half spectrum as complex numbers; FFTW_AMD_R2R_POST_* = the
    untangle step applies that r2r epilogue and writes reals of stride cs instead
    (even lengths only; returns 1 when the epilogue was fused, 0 when the caller
@@ -1483,8 +1578,10 @@ static int emit_r2c_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc in, i64 rs,
     i64 half = nl / 2 + 1;
     int j;
     if (ps == 0) { ps = 2 * rs; pim = rs; }
-    if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
-        (axis_pass_count(p, nl / 4) < half_axis_pass_count(p, nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
+    if (epi == 0 && pre == 0 && ps == 2 && pim == 1 && cs == 2 && emit_r2c_decimated(p, nl, &ax, in, out)) return 0;
+    if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS && !getenv("FFTW_AMD_NO_RADIX4") &&
+        ((axis_pass_count(p, nl / 4) < half_axis_pass_count(p, nl / 2) && radix4_passes_have_kernels(p, nl / 4)) ||
+         getenv("FFTW_AMD_FORCE_RADIX4"))) {
         /* n = 4m: two complex DFTs of size m on (x[4j], x[4j+1]) and (x[4j+2], x[4j+3]),
            then the radix-4 untangle -- the reference's rdft2-ct-dit/4 + hc2cfdft_4 plan,
            chosen when m needs fewer passes than n/2 (n = 2^22: m = 2^20 is 1024 x 1024) */
@@ -1679,8 +1776,9 @@ static void emit_c2r_axis(plan *p, i64 nl, const fa_axis *axp, fa_loc cur, i64 c
     fa_axis ax = *axp;
     int j;
     if (ps == 0) { ps = 2 * rs; pim = rs; }
-    if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS &&
-        (axis_pass_count(p, nl / 4) < half_axis_pass_count(p, nl / 2) || getenv("FFTW_AMD_FORCE_RADIX4"))) {
+    if (nl % 4 == 0 && nl >= 8 && ax.nloops < FA_MAXLOOPS && !getenv("FFTW_AMD_NO_RADIX4") &&
+        ((axis_pass_count(p, nl / 4) < half_axis_pass_count(p, nl / 2) && radix4_passes_have_kernels(p, nl / 4)) ||
+         getenv("FFTW_AMD_FORCE_RADIX4"))) {
         /* transpose of the radix-4 r2c plan: tangle into two quarter-length
            spectra, two backward complex DFTs of size m straight into the real array */
         i64 m = nl / 4, zts, lts[FA_MAXLOOPS + 1], total;
@@ -2733,6 +2831,7 @@ char *fa_sprint(const plan *p) {
             else if (d->variant == FFTW_AMD_K_C2R) sapp(s, cap, &len, d->aux_valid ? (d->aux_buf > 0 ? "c2r-rows+r2r-pre+post" : "c2r-rows+r2r-pre") : "c2r-rows");
             else if (d->variant == FFTW_AMD_K_P1024) sapp(s, cap, &len, "reg32x32");
             else if (d->variant == FFTW_AMD_K_RR) sapp(s, cap, &len, "reg2");
+            else if (d->variant == FFTW_AMD_K_R3 && (d->flags & FFTW_AMD_F_REAL_DEC)) sapp(s, cap, &len, "reg3+real-decimated");
             else if (d->variant == FFTW_AMD_K_R3) sapp(s, cap, &len, (d->flags & FFTW_AMD_F_LO_DFT) ? (d->tile_lo_n == 4 ? "reg3+dft4-across-rows" : "reg3+dft2-across-rows") : "reg3");
             else if (d->variant == FFTW_AMD_K_R1) sapp(s, cap, &len, "reg1");
             else if (d->variant == FFTW_AMD_K_BLUE) sapp(s, cap, &len, "bluestein-rows n=%lld", (long long)d->aux_n);

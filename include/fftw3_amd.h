@@ -239,9 +239,18 @@ enum {
                                       length-L pass, stores the real pairs (dst_im = 1) */
     FFTW_AMD_F_NT_IN     = 1 << 12,/* the source is read once per execution: nontemporal loads */
     FFTW_AMD_F_NT_OUT    = 1 << 13,/* the destination is not read again by this plan: nontemporal stores */
-    FFTW_AMD_F_LO_DFT    = 1 << 14 /* pass: the inner tile component is transformed too -- a DFT of length tile_lo_n across the
+    FFTW_AMD_F_LO_DFT    = 1 << 14,/* pass: the inner tile component is transformed too -- a DFT of length tile_lo_n across the
                                       tile's tile_lo_n sequences (no twiddle), i.e. the step is the 2-D DFT tile_lo_n x L of every
                                       tile (pass3q.hpp: four rows of 4096 points, the last trip of a 4096 x 4096 transform) */
+    FFTW_AMD_F_REAL_DEC  = 1 << 15 /* pass: the last trip of a two-trip r2c transform of n = L1 x L real points (pass3t_kernel,
+                                      RD = 1).  The tile dim runs over the rows k1 = 0 ... L1 / 2 (dim_n[0] = L1 / 2 + 1) of the
+                                      scratch image Z[k1][c] (rows at dim_is[0], pairs at is_l) left by the complex pass of
+                                      length L1 over the real input read as pairs; row k1 is loaded as
+                                      A[2c] = (Z[k1][c] + conj Z[L1-k1][c]) / 2, A[2c+1] = (Z[k1][c] - conj Z[L1-k1][c]) / 2i,
+                                      multiplied by the input twiddle and transformed; output k2 < L / 2 goes to
+                                      k1 dim_os[0] + k2 os_l, the others conjugated to (L1-k1) dim_os[0] + (L-1-k2) os_l
+                                      (not for k1 = 0 and L1 / 2, whose second halves repeat their first; X[n / 2] comes from
+                                      row 0).  No fallback executor: planned only for aligned interleaved arrays */
 };
 
 int fftw_amd_plan_num_steps(const fftw_plan p);

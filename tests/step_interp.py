@@ -146,6 +146,43 @@ class Interp(object):
                 c = np.fft.ifft(np.fft.fft(b, axis=0) * kern, axis=0) * L
                 _store(dst, do2, s.dst_im, s.flags & fa.F_SWAP_OUT, c[:n] * np.conj(chirp))
                 return
+            if s.flags & fa.F_REAL_DEC:
+                # last trip of a two-trip r2c of n = L1 x L real points (include/fftw3_amd.h): dims[0] = rows
+                # k1 = 0 ... L1 / 2 of the scratch image Z[k1][c]; the row's inputs are the separated real-column
+                # spectra; outputs k2 < L / 2 in place, the others conjugated at the mirrored index
+                assert (s.flags & fa.F_TW_IN) and s.tw_n and dtw[0] == 1 and s.src_im == 1 and s.dst_im == 1
+                nrow = dn[0]
+                L1 = 2 * (nrow - 1)
+                k1 = idx[0]
+                km = np.where(k1 == 0, 0, L1 - k1)
+                rest_s = np.zeros_like(l)
+                rest_d = np.zeros_like(l)
+                for i, gi in enumerate(idx):
+                    if i:
+                        rest_s = rest_s + gi * dis[i]
+                        rest_d = rest_d + gi * dos[i]
+                c = l >> 1
+                o1 = sbase + c * s.is_l + k1 * dis[0] + rest_s
+                o2 = sbase + c * s.is_l + km * dis[0] + rest_s
+                Z1 = src[o1] + 1j * src[o1 + 1]
+                Z2 = src[o2] + 1j * src[o2 + 1]
+                x = np.where((l & 1) == 1, -0.5j * (Z1 - np.conj(Z2)), 0.5 * (Z1 + np.conj(Z2)))
+                m = l * twb
+                assert m.max() < s.tw_n
+                y = np.fft.fft(x * np.conj(self.tw2(s, m)), axis=0)
+                shape = y.shape
+                k2 = np.broadcast_to(l, shape)
+                k1b = np.broadcast_to(k1, shape)
+                direct = (k2 < L // 2) | ((k1b == 0) & (k2 == L // 2))
+                mirror = (k2 >= L // 2) & (k1b != 0) & (2 * k1b != L1)
+                y = np.where((k1b == 0) & ((k2 == 0) | (k2 == L // 2)), y.real + 0j, y)
+                od = np.broadcast_to(dbase + k2 * s.os_l + k1 * dos[0] + rest_d, shape)
+                om = np.broadcast_to(dbase + (L - 1 - k2) * s.os_l + (L1 - k1) * dos[0] + rest_d, shape)
+                dst[od[direct]] = y.real[direct]
+                dst[od[direct] + 1] = y.imag[direct]
+                dst[om[mirror]] = y.real[mirror]
+                dst[om[mirror] + 1] = -y.imag[mirror]
+                return
             if s.flags & fa.F_C2R_ROWS:
                 # fused c2r: L + 1 spectrum entries per row -> 2L reals stored as L (re, im) pairs
                 g2 = _grids([L + 1] + dn)

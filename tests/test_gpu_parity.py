@@ -71,6 +71,46 @@ def test_two_trips_with_both_lengths_above_1024(torch_dev, n):
     assert aerror(y, oracle_dft(x, (n,), b, +1).reshape(b, n)) < TOL
 
 
+@pytest.mark.parametrize("n", [1 << 22, 1 << 21, 2048 * 1000, 2048 * 1920, 2048 * 256])
+def test_r2c_in_two_trips(torch_dev, n, monkeypatch):
+    """a long real transform n = L1 x 2048 decimated over the real data (emit_r2c_decimated): the complex pass of length
+    L1 over the input read as pairs, then rows with the two real columns separated on the load side and the upper
+    half stored conjugated at the mirrored index (FFTW_AMD_F_REAL_DEC) -- two trips where the half-length plans take
+    three (a FFTW_MEASURE candidate, FFTW_AMD_REAL_DEC=1 here); out of place, in place (FFTW's padded layout), and
+    against the three-trip plan"""
+    torch, dev = torch_dev
+    monkeypatch.setenv("FFTW_AMD_REAL_DEC", "1")     # off under FFTW_ESTIMATE: it only ties with the three-trip plans
+    rng = np.random.default_rng(n)
+    b = 3
+    xr = rrand(rng, b, n)
+    want = oracle_r2c(xr, (n,), b).reshape(b, n // 2 + 1)
+    xd = torch.from_numpy(xr).to(dev)
+    yd = torch.zeros(b, n // 2 + 1, dtype=torch.complex128, device=dev)
+    p = fa.plan_many_dft_r2c(1, [n], b, xd, None, 1, n, yd, None, 1, n // 2 + 1)
+    assert len(p.steps()) == 2 and "real-decimated" in p.sprint(), p.sprint()
+    p.execute()
+    torch.cuda.synchronize()
+    got = yd.cpu().numpy()
+    assert aerror(got, want) < TOL
+    assert got[:, 0].imag.max() == 0.0 and got[:, n // 2].imag.max() == 0.0
+    # in place: rows of n + 2 reals
+    pd = torch.zeros(b, n + 2, dtype=torch.float64, device=dev)
+    pd[:, :n] = xd
+    q = fa.plan_many_dft_r2c(1, [n], b, pd, None, 1, n + 2, pd, None, 1, n // 2 + 1)
+    assert "real-decimated" in q.sprint(), q.sprint()
+    q.execute()
+    torch.cuda.synchronize()
+    assert aerror(torch.view_as_complex(pd.reshape(b, n // 2 + 1, 2)).cpu().numpy(), want) < TOL
+    # the three-trip plan of the same transform agrees to rounding
+    monkeypatch.delenv("FFTW_AMD_REAL_DEC")
+    y3 = torch.zeros_like(yd)
+    p3 = fa.plan_many_dft_r2c(1, [n], b, xd, None, 1, n, y3, None, 1, n // 2 + 1)
+    assert "real-decimated" not in p3.sprint()
+    p3.execute()
+    torch.cuda.synchronize()
+    assert aerror(y3.cpu().numpy(), want) < TOL
+
+
 def test_sweep_1_to_100_and_pow2(torch_dev):
     """the reference's size sweep (fftw/tests/check.pl:126-173), forward and backward"""
     rng = np.random.default_rng(7)

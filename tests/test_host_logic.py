@@ -464,6 +464,54 @@ def test_split_models_keep_the_factorisation_exact_and_prefer_measured_winners()
     assert _pass_lengths(p) == [1920, 1080], p.sprint()
 
 
+def test_r2c_decimated_over_the_real_data(monkeypatch):
+    """cfg.real_dec (FFTW_AMD_REAL_DEC=1, a FFTW_MEASURE candidate): n = L1 x 2048 real points as the complex pass of
+    length L1 over the input read as pairs + the rows step with FFTW_AMD_F_REAL_DEC -- two steps whose list computes
+    the half spectrum under the numpy interpreter, out of place and in FFTW's padded in-place layout; not planned
+    for FFTW_UNALIGNED, for lengths that are no multiple of 2048, or by default"""
+    rng = np.random.default_rng(11)
+    n, b = 2048 * 256, 3
+    xr = rrand(rng, b, n)
+    y = np.zeros((b, n // 2 + 1), dtype=complex)
+    assert "real-decimated" not in fa.plan_many_dft_r2c(1, [n], b, xr, None, 1, n, y, None, 1, n // 2 + 1).sprint()
+    monkeypatch.setenv("FFTW_AMD_REAL_DEC", "1")
+    p = fa.plan_many_dft_r2c(1, [n], b, xr, None, 1, n, y, None, 1, n // 2 + 1)
+    st = p.steps()
+    assert len(st) == 2 and "real-decimated" in p.sprint(), p.sprint()
+    assert (st[1].flags & fa.F_REAL_DEC) and (st[1].flags & fa.F_TW_IN) and st[1].dim_n[0] == 256 // 2 + 1 and st[1].tile == 8
+    run_plan_on_host(p, xr, y)
+    ref = oracle_r2c(xr, (n,), b).reshape(b, n // 2 + 1)
+    assert aerror(y, ref) < TOL
+    assert np.all(y[:, 0].imag == 0.0) and np.all(y[:, n // 2].imag == 0.0)
+    pad = np.zeros((b, n + 2))
+    pad[:, :n] = xr
+    q = fa.plan_many_dft_r2c(1, [n], b, pad, None, 1, n + 2, pad, None, 1, n // 2 + 1)
+    assert "real-decimated" in q.sprint()
+    run_plan_on_host(q, pad, pad)
+    assert aerror(pad.reshape(b, n // 2 + 1, 2)[..., 0] + 1j * pad.reshape(b, n // 2 + 1, 2)[..., 1], ref) < TOL
+    assert "real-decimated" not in fa.plan_many_dft_r2c(1, [n], b, xr, None, 1, n, y, None, 1, n // 2 + 1,
+                                                         fa.ESTIMATE | fa.UNALIGNED).sprint()
+    m = 2000 * 300
+    assert "real-decimated" not in fa.plan_many_dft_r2c(1, [m], b, np.zeros((b, m)), None, 1, m,
+                                                         np.zeros((b, m // 2 + 1), dtype=complex), None, 1, m // 2 + 1).sprint()
+
+
+def test_radix4_real_plans_only_where_their_pair_tiles_have_register_kernels():
+    """n = 4m through two quarter-length transforms on interleaved pairs (r2c-untangle4 / c2r-tangle4) only when a
+    multi-pass m is a power of two: other lengths would put a pass on the runtime-radix LDS kernel (3 932 160: 7.9 ms
+    per 4 GiB against 4.3 for the half-length plan)"""
+    for n in (3932160, 3145728, 4096000):
+        xr = np.zeros(8)
+        y = np.zeros(8, dtype=complex)
+        p = fa.plan_many_dft_r2c(1, [n], 64, xr, None, 1, n, y, None, 1, n // 2 + 1, fa.ESTIMATE)
+        assert "lds:" not in p.sprint() and "untangle4" not in p.sprint(), p.sprint()
+        q = fa.plan_many_dft_c2r(1, [n], 64, y, None, 1, n // 2 + 1, xr, None, 1, n, fa.ESTIMATE)
+        assert "lds:" not in q.sprint(), q.sprint()
+    xr = np.zeros(8)
+    y = np.zeros(8, dtype=complex)
+    assert "untangle4" in fa.plan_many_dft_r2c(1, [1 << 22], 64, xr, None, 1, 1 << 22, y, None, 1, (1 << 21) + 1, fa.ESTIMATE).sprint()
+
+
 def test_streaming_access_flags_only_on_the_callers_side_and_only_for_large_batches():
     """FFTW_AMD_F_NT_IN / NT_OUT (mark_streaming_accesses): set on the step that reads the caller's input once
     and on the step that writes the output nobody reads back, never on scratch traffic, and not at all when the
