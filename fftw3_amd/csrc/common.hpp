@@ -151,6 +151,25 @@ FA_DEV cplx tw2(const cplx *lo, const cplx *hi, int shift, i64 m) {
     return c_mul(a, b);
 }
 
+/* the same for WAVE-UNIFORM indices m[0 .. N) (the caller guarantees it, e.g. through readfirstlane): 2 N scalar
+   loads through the constant cache and one wait, instead of 2 N vector loads that each fetch one and the same entry
+   for 64 lanes */
+template <int N> FA_DEV void tw2_uniform(cplx *out, const cplx *lo, const cplx *hi, int shift, const i64 *m) {
+    fa_d2 va[N], vb[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        const cplx *pl = lo + (m[s] & ((1LL << shift) - 1));
+        const cplx *ph = hi + (m[s] >> shift);
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(va[s]) : "s"(pl) : "memory");
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(vb[s]) : "s"(ph) : "memory");
+    }
+#pragma unroll
+    for (int s = 0; s < N; ++s)      /* the first wait covers all; the operands tie every use to a wait */
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(va[s]), "+s"(vb[s]));
+#pragma unroll
+    for (int s = 0; s < N; ++s) out[s] = c_mul(c_make(va[s].x, va[s].y), c_make(vb[s].x, vb[s].y));
+}
+
 static inline i64 iabs64(i64 v) { return v < 0 ? -v : v; }
 
 /* offsets applied for the current batch chunk: user buffers advance, scratch

@@ -337,6 +337,13 @@ template <int R1, int R2, int R3, int NT = 256> struct P3TGeom {
    conjugate of the others at n - (k1 + L1 k2) = (L1 - k1) + L1 (L - 1 - k2) -- the half spectrum 0 ... n / 2, every
    store a run of T consecutive outputs.  Reference counterpart: the rdft2 Cooley-Tukey node over real codelets,
    hc2cf / r2cf (fftw/rdft_scalar/r2cf/hc2cfdft_*.c under ct_hc2c_direct_apply, fftw/fftw_api.c:5831). */
+/* FA_P3T_TIMELINE (tests/micro/p3t_timeline.hip only, never in the product): wave 0 of every workgroup leaves
+   wall-clock stamps at the phase boundaries in a.dbg[16 * blockIdx.x + k] */
+#ifdef FA_P3T_TIMELINE
+#define FA_P3T_STAMP(k) do { if (tid == 0) a.dbg[(i64)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define FA_P3T_STAMP(k) do { } while (0)
+#endif
 template <int R1, int R2, int R3, bool IN_T, int HAS_TW, int NT = 256, int RD = 0>
 __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1)
 pass3t_kernel(const P1024Args a) {
@@ -345,6 +352,7 @@ pass3t_kernel(const P1024Args a) {
     typedef P3TGeom<R1, R2, R3, NT> G;
     constexpr int M = G::M, T = G::T, QA = G::QA, QB = G::QB, QC = G::QC;
     const int tid = threadIdx.x;
+    FA_P3T_STAMP(0);
 
     i64 tile, soff, doff, twb;
     fa_block_offsets<true>(a, tile, soff, doff, twb);
@@ -365,6 +373,29 @@ pass3t_kernel(const P1024Args a) {
         aa[u] = IN_T ? g / T : g % M;
         t = t < Tcur - 1 ? t : Tcur - 1;              /* sequences past the end: redo the last one */
         at[u] = t;
+    }
+    /* the input twiddle's per-item factor w^(q a): its two table loads go out BEFORE the data loads, so that their
+       latency hides behind the tile's (they used to start when the data had arrived) */
+    cplx twb_in[HAS_TW == 2 ? QA : 1];
+    i64 twq[HAS_TW == 2 ? QA : 1];
+    if constexpr (HAS_TW == 2) {
+#pragma unroll
+        for (int u = 0; u < QA; ++u) {
+            i64 q = q0 + (i64)at[u] * a.dtw[0];
+            if constexpr (!IN_T && M % 64 == 0 && NT % 64 == 0) {
+                /* rows form with M a multiple of the wave: a wave's 64 butterflies lie in ONE row, so q and the
+                   powers w^(q M 2^s) are wave-uniform -- scalar loads instead of 2 x bits scattered vector loads
+                   per butterfly (tests/micro/p3t_timeline.hip: the input twiddle was the longest phase of the tile) */
+                q = ((i64)__builtin_amdgcn_readfirstlane((int)(q >> 32)) << 32) |
+                    (i64)(unsigned)__builtin_amdgcn_readfirstlane((int)q);
+            }
+            twq[u] = q;
+            twb_in[u] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * aa[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QA; ++u) {
+        const int t = at[u];
         if constexpr (RD == 1) {
             /* element l = aa + M i of row k1 is A[k1][l]: pair c = l / 2 of the rows k1 and L1 - k1 of Z */
             const i64 k1 = t0 + t, L1 = 2 * (a.dn[0] - 1);
@@ -386,6 +417,10 @@ pass3t_kernel(const P1024Args a) {
         const i64 step = (i64)M * a.is_l;
         ld_run<R1>(x[u], p, step, (a.flags & FFTW_AMD_F_NT_IN) != 0);
     }
+#ifdef FA_P3T_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);
+    FA_P3T_STAMP(7);                               /* wave 0's loads have arrived */
+#endif
     if (a.flags & FFTW_AMD_F_SWAP_IN) {
 #pragma unroll
         for (int u = 0; u < QA; ++u)
@@ -396,11 +431,18 @@ pass3t_kernel(const P1024Args a) {
     for (int u = 0; u < QA; ++u) {
         if (HAS_TW == 2) {
             /* conj(w_N^((a + M i) q)) on the input */
-            const i64 q = q0 + (i64)at[u] * a.dtw[0];
-            cplx base = tw2(a.tw_lo, a.tw_hi, a.tw_shift, q * aa[u]);
+            const i64 q = twq[u];
+            const cplx base = twb_in[u];
             cplx pw[RB<R1>::bits];
+            if constexpr (!IN_T && M % 64 == 0 && NT % 64 == 0) {
+                i64 mm[RB<R1>::bits];
 #pragma unroll
-            for (int s = 0; s < RB<R1>::bits; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * M) << s);
+                for (int s = 0; s < RB<R1>::bits; ++s) mm[s] = (q * M) << s;
+                tw2_uniform<RB<R1>::bits>(pw, a.tw_lo, a.tw_hi, a.tw_shift, mm);
+            } else {
+#pragma unroll
+                for (int s = 0; s < RB<R1>::bits; ++s) pw[s] = tw2(a.tw_lo, a.tw_hi, a.tw_shift, (q * M) << s);
+            }
             TwTreeR<R1, RB<R1>::bits - 1, 0, true, false>::run(x[u], pw, base);
         }
         RB<R1>::run(x[u]);
@@ -410,6 +452,7 @@ pass3t_kernel(const P1024Args a) {
         TwTreeR<R1, RB<R1>::bits - 1, 0, false, true>::run(x[u], pw, c_make(1.0, 0.0));
     }
 
+    FA_P3T_STAMP(1);
     /* ---- exchange 1.  Column form: E1[d1][a][t]; rows form: E1[t][d1][a].  Stage B owners:
        column form (t, a2, d1) with t fastest; rows form (d1, a2, t) with d1 fastest. */
     cplx y[QB][R2];
@@ -444,6 +487,7 @@ pass3t_kernel(const P1024Args a) {
         for (int i = 0; i < R2; ++i) y[v][i].y = plane[FA_E1(bt[v], bd1[v], ba2[v] + R3 * i)];
     __syncthreads();
 #undef FA_E1
+    FA_P3T_STAMP(2);
 
     /* ---- stage B: DFT-R2 over i2, twiddle w_M^(a2 d2) = wL[a2 d2 R1] */
 #pragma unroll
@@ -454,6 +498,7 @@ pass3t_kernel(const P1024Args a) {
         for (int s = 0; s < RB<R2>::bits; ++s) pw[s] = a.w1024[((ba2[v] << s) * R1) % G::L];
         TwTreeR<R2, RB<R2>::bits - 1, 0, false, true>::run(y[v], pw, c_make(1.0, 0.0));
     }
+    FA_P3T_STAMP(3);
 
     /* ---- exchange 2 -> stage C owners (t fastest, then d1, then d2): transposed / column store.
        Column form: E2[d2][a2][d1][t]; rows form: the same with t padded to an odd stride. */
@@ -490,6 +535,7 @@ pass3t_kernel(const P1024Args a) {
 #pragma unroll
         for (int q = 0; q < R3; ++q) z[w][q].y = plane[FA_E2(ct[w], cd2[w], q, cd1[w])];
 #undef FA_E2
+    FA_P3T_STAMP(4);
 
     /* ---- stage C: DFT-R3 over a2, optional output twiddle, store X[d1 + R1 d2 + R1 R2 c] */
     const bool sw = (a.flags & FFTW_AMD_F_SWAP_OUT) != 0;
@@ -560,6 +606,11 @@ pass3t_kernel(const P1024Args a) {
             st_sel(p + c * step, v, (a.flags & FFTW_AMD_F_NT_OUT) != 0);
         }
     }
+#ifdef FA_P3T_TIMELINE
+    FA_P3T_STAMP(5);                               /* stores issued */
+    __builtin_amdgcn_s_waitcnt(0);
+    FA_P3T_STAMP(6);                               /* wave 0's stores acknowledged */
+#endif
 }
 
 #endif /* FA_PASS3G_HPP */

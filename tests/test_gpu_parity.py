@@ -355,11 +355,12 @@ def test_rows_of_8192_and_16384_in_one_trip(torch_dev, n):
     assert len(one.steps()) == 2, one.sprint()
 
 
-@pytest.mark.parametrize("k,lens", [(22, [128, 128, 256]), (23, [128, 128, 512]), (24, [128, 128, 1024]),
+@pytest.mark.parametrize("k,lens", [(22, [2048, 2048]), (23, [128, 128, 512]), (24, [128, 128, 1024]),
                                     (25, [512, 128, 512])])
 def test_three_pass_powers_of_two(torch_dev, k, lens):
-    """2^22 ... 2^25: the three-pass split comes from the planner's per-position cost table
-    (pow2_three_pass_split); forward c2c against the oracle, and r2c of twice the length"""
+    """2^23 ... 2^25: the three-pass split comes from the planner's per-position cost table
+    (pow2_three_pass_split); 2^22 = 2048 x 2048 takes two trips on the 512-item kernels since round 3; forward c2c
+    against the oracle, and r2c of twice the length"""
     torch, dev = torch_dev
     n = 1 << k
     rng = np.random.default_rng(k)
