@@ -496,6 +496,36 @@ def test_measure_mode_records_wisdom(torch_dev):
     fa.forget_wisdom()
 
 
+def test_measure_mode_times_the_decimated_r2c_plan_too(torch_dev):
+    """for r2c problems FFTW_MEASURE also times the plan decimated over the real data (cfg.real_dec); whichever wins,
+    the wisdom round-trips (the candidate is bit 16 of the wisdom line's flag field) and both plans compute the
+    oracle's answer"""
+    torch, dev = torch_dev
+    fa.forget_wisdom()
+    n, b = 1 << 20, 24
+    rng = np.random.default_rng(21)
+    xr = rrand(rng, b, n)
+    want = oracle_r2c(xr, (n,), b).reshape(b, n // 2 + 1)
+    xd = torch.from_numpy(xr).to(dev)
+    yd = torch.zeros(b, n // 2 + 1, dtype=torch.complex128, device=dev)
+    p = fa.plan_many_dft_r2c(1, [n], b, xd, None, 1, n, yd, None, 1, n // 2 + 1, fa.MEASURE)
+    text = fa.export_wisdom_to_string()
+    picked = "real-decimated" in p.sprint()
+    xd.copy_(torch.from_numpy(xr))
+    p.execute()
+    torch.cuda.synchronize()
+    assert aerror(yd.cpu().numpy(), want) < TOL
+    fa.forget_wisdom()
+    assert fa.import_wisdom_from_string(text) == 1
+    p2 = fa.plan_many_dft_r2c(1, [n], b, xd, None, 1, n, yd, None, 1, n // 2 + 1, fa.ESTIMATE | fa.WISDOM_ONLY)
+    assert ("real-decimated" in p2.sprint()) == picked, (p.sprint(), p2.sprint(), text)
+    yd.zero_()
+    p2.execute()
+    torch.cuda.synchronize()
+    assert aerror(yd.cpu().numpy(), want) < TOL
+    fa.forget_wisdom()
+
+
 def test_host_arrays_are_staged(torch_dev):
     """plain host pointers (numpy) take the PCIe staging path, incl. gaps in the output"""
     rng = np.random.default_rng(2)
