@@ -318,8 +318,16 @@ template <int R1, int R2, int R3, int NT = 256> struct P3TGeom {
     static constexpr int TP = T + 1;                               /* odd stride of t where it is not fastest */
     /* column form: element (d1, a, t) at (d1 * M + a) * T + t, rows of d1 padded to stride = T mod 32 */
     static constexpr int S1C = M * T + ((32 + T - (M * T) % 32) % 32);
-    static constexpr int S2C = R3 * R1 * T + ((32 + T - (R3 * R1 * T) % 32) % 32);
-    static constexpr int S1R = M + (M % 2 == 0 ? 1 : 0);           /* rows form: as P3GGeom */
+    /* exchange 2, column form: (d2, a2, d1, t) at d2 * S2C + a2 * A2C + d1 * T + t.  The stage-B owners write with
+       t fastest, then a2: with A2C = R1 T a multiple of 16 doubles a quarter wave (8 t x 2 a2) hits 8 bank pairs
+       twice, so the 512-item form pads A2C to 8 mod 16 (the 256-item form keeps its 2 x 80 KiB of LDS per CU) */
+    static constexpr int A2C = R1 * T + ((NT > 256 && (R1 * T) % 16 == 0 && T == 8) ? 8 : 0);
+    static constexpr int S2C = R3 * A2C + ((32 + T - (R3 * A2C) % 32) % 32);
+    /* rows form, exchange 1: (t, d1, a) at (t * R1 + d1) * S1R + a.  The stage-B owners read with d1 fastest, then
+       a2: a quarter wave is R1 values of d1 x 16 / R1 values of a2, conflict-free when S1R = 16 / R1 mod 16
+       (512-item form, R1 a power of two; otherwise the odd stride of P3GGeom) */
+    static constexpr int S1R_ODD = M + (M % 2 == 0 ? 1 : 0);
+    static constexpr int S1R = (NT > 256 && (R1 == 2 || R1 == 4 || R1 == 8) && M % 16 == 0) ? M + 16 / R1 : S1R_ODD;
     static constexpr int E1 = (R1 * S1C > T * R1 * S1R ? R1 * S1C : T * R1 * S1R);
     static constexpr int E2C = R2 * S2C;
     static constexpr int E2R = R2 * R3 * R1 * TP;
@@ -513,7 +521,7 @@ pass3t_kernel(const P1024Args a) {
         cd1[w] = (j / T) % R1;
         cd2[w] = j / (T * R1);
     }
-#define FA_E2(t, d2, a2, d1) (IN_T ? ((d2) * G::S2C + ((a2) * R1 + (d1)) * T + (t)) \
+#define FA_E2(t, d2, a2, d1) (IN_T ? ((d2) * G::S2C + (a2) * G::A2C + (d1) * T + (t)) \
                                    : ((((d2) * R3 + (a2)) * R1 + (d1)) * G::TP + (t)))
 #pragma unroll
     for (int v = 0; v < QB; ++v)
