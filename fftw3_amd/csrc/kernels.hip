@@ -346,19 +346,53 @@ struct CopyArgs {
     int flags;
 };
 
+/* U virtual blocks (U x 256 consecutive inner indices) per trip of a workgroup: the U index chains (table entry ->
+   element -> store) of a work-item are independent, so their loads overlap.  U = 4 for plain / padded / table
+   copies (Bluestein's chirp products: 3.8 -> 3.0 ms per 2 GiB batch of n = 10007); the PERMUTED copies of Rader's
+   gather / scatter stay at U = 1 -- they are bound by their 16-byte accesses to 128-byte lines (3.5 ms per 2 GiB
+   where a pass takes 1.5) and four in flight per item change nothing (profiles/r03_prime_plan_steps.txt) */
+template <int U>
 __global__ void __launch_bounds__(256) copy_kernel(const CopyArgs a) {
-    for (i64 vb = blockIdx.x; vb < a.e.nvb; vb += gridDim.x) {
-        i64 k, soff, doff;
-        if (!elem_index(a.e, vb, &k, &soff, &doff)) continue;
-        cplx v = c_make(0.0, 0.0);
-        if (k < a.Kvalid) {
-            i64 ks = (a.flags & FFTW_AMD_F_PERM_SRC) ? a.perm[k] : k;
-            v = load_elem<false>(a.src, soff + ks * a.is_k, a.src_im, a.flags);
+    const i64 ngroups = (a.e.nvb + U - 1) / U;
+    /* a permuted copy touches every 128-byte line of a row eight times, 16 bytes at a time: with the virtual blocks
+       dealt round-robin all eight XCDs (workgroup b runs on XCD b % 8) fill / write back every line of every row.
+       Keeping each ROW on one XCD leaves that to one L2: rows of 12288 points 3.5 -> 2.8 ms per 2 GiB, rows of 2^16
+       points (1 MiB of the 4 MiB L2) unchanged */
+    const i64 nrows = a.e.nvb / a.e.nblk;
+    const bool by_rows = U == 1 && (gridDim.x & 7) == 0 && nrows >= 8;
+    const i64 xcd = blockIdx.x & 7, per = by_rows ? (gridDim.x >> 3) : gridDim.x;
+    for (i64 j = by_rows ? (blockIdx.x >> 3) : blockIdx.x; ; j += per) {
+        i64 g = j;
+        if (by_rows) {
+            const i64 rr = j / a.e.nblk, row = xcd + 8 * rr;
+            if (row >= nrows) break;
+            g = row * a.e.nblk + (j - rr * a.e.nblk);
+        } else if (g >= ngroups) break;
+        i64 k[U], soff[U], doff[U], ks[U];
+        bool ok[U];
+        cplx v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const i64 vb = g * U + u;
+            ok[u] = vb < a.e.nvb && elem_index(a.e, vb, &k[u], &soff[u], &doff[u]);
+            if (!ok[u]) { k[u] = 0; soff[u] = 0; doff[u] = 0; }
         }
-        if (a.flags & FFTW_AMD_F_MUL_TABLE) v = c_mul(v, a.tab[k]);
-        if (a.flags & FFTW_AMD_F_MUL_CONJ) v = c_mulc(v, a.tab[k]);
-        i64 kd = (a.flags & FFTW_AMD_F_PERM_DST) ? a.perm[k] : k;
-        store_elem<false>(a.dst, doff + kd * a.os_k, a.dst_im, a.flags, v);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            ks[u] = (ok[u] && (a.flags & FFTW_AMD_F_PERM_SRC)) ? a.perm[k[u]] : k[u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = c_make(0.0, 0.0);
+            if (ok[u] && k[u] < a.Kvalid) v[u] = load_elem<false>(a.src, soff[u] + ks[u] * a.is_k, a.src_im, a.flags);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            if (a.flags & FFTW_AMD_F_MUL_TABLE) v[u] = c_mul(v[u], a.tab[k[u]]);
+            if (a.flags & FFTW_AMD_F_MUL_CONJ) v[u] = c_mulc(v[u], a.tab[k[u]]);
+            const i64 kd = (a.flags & FFTW_AMD_F_PERM_DST) ? a.perm[k[u]] : k[u];
+            store_elem<false>(a.dst, doff[u] + kd * a.os_k, a.dst_im, a.flags, v[u]);
+        }
     }
 }
 
@@ -1546,8 +1580,16 @@ static int launch_step_kind(const fftw_amd_step_desc *d, double *const *bufs,
         CopyArgs ca;
         dim3 grid;
         if (!fill_copy_args(&ca, d, bufs, tables, cs, cn, &grid)) return 0;
-        if (d->kind == FFTW_AMD_STEP_COPY)
-            hipLaunchKernelGGL(copy_kernel, grid, dim3(256), 0, st, ca);
+        if (d->kind == FFTW_AMD_STEP_COPY) {
+            if (d->flags & (FFTW_AMD_F_PERM_SRC | FFTW_AMD_F_PERM_DST)) {
+                if (grid.x >= 8) grid.x &= ~7u;          /* rows stay on one XCD: a grid of whole rounds of the eight */
+                hipLaunchKernelGGL(copy_kernel<1>, grid, dim3(256), 0, st, ca);
+            } else {
+                const i64 ngroups = (ca.e.nvb + 3) / 4;
+                if ((i64)grid.x > ngroups) grid.x = (unsigned)ngroups;
+                hipLaunchKernelGGL(copy_kernel<4>, grid, dim3(256), 0, st, ca);
+            }
+        }
         else
             hipLaunchKernelGGL(herm_expand_kernel, grid, dim3(256), 0, st, ca);
         return 0;
