@@ -360,6 +360,14 @@ pass3t_kernel(const P1024Args a) {
     typedef P3TGeom<R1, R2, R3, NT> G;
     constexpr int M = G::M, T = G::T, QA = G::QA, QB = G::QB, QC = G::QC;
     const int tid = threadIdx.x;
+#ifdef FA_P3T_TIMELINE
+    /* probe only: delay every other workgroup of the first round by a.lo_sh x 0.64 us (are the lock-step phases of a
+       one-workgroup-per-CU kernel worth breaking?) */
+    if (a.lo_sh > 0 && blockIdx.x < 256 && (blockIdx.x & 8)) {
+        const long long t_go = wall_clock64() + 64LL * a.lo_sh;
+        while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     FA_P3T_STAMP(0);
 
     i64 tile, soff, doff, twb;

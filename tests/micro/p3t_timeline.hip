@@ -58,6 +58,7 @@ static void run(const char *name, P1024Args pa, int nblocks, long long *dbg_dev,
 
 int main(int argc, char **argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 2;                     // transforms of 2048 x 2048 complex
+    const int stagger = argc > 2 ? atoi(argv[2]) : 0;               // delay of every other first-round workgroup, x 0.64 us
     const i64 N = 2048LL * 2048;
     double *src, *dst;
     cplx *w, *lo, *hi;
@@ -78,7 +79,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&dbg, (size_t)nblocks * 16 * 8));
     P1024Args pa = P1024Args();
     pa.src = src; pa.dst = dst; pa.w1024 = w; pa.tw_lo = lo; pa.tw_hi = hi; pa.tw_shift = 11;
-    pa.ndims = 2; pa.flags = 0; pa.dbg = dbg; pa.ntiles = 256;
+    pa.ndims = 2; pa.flags = 0; pa.dbg = dbg; pa.ntiles = 256; pa.lo_sh = stagger;
     for (int i = 0; i < FFTW_AMD_MAX_DIMS; ++i) { pa.dn[i] = 1; pa.dis[i] = 0; pa.dos[i] = 0; pa.dtw[i] = 0; }
     // pass 1: columns of the [2048][2048] view, in place order
     pa.is_l = 2 * 2048; pa.os_l = 2 * 2048;
