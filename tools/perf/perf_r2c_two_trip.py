@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 import fftw3_amd as fa
 buf = torch.rand((4 << 30) // 8, dtype=torch.float64, device="cuda") - 0.5
-for n in ([int(os.environ["PERF_N"])] if os.environ.get("PERF_N") else (1 << 22, 1 << 21, 1 << 20, 2048 * 1920, 2048 * 1000, 2048 * 1536, 2048 * 1280, 2048 * 1080, 2048 * 768, 2048 * 960, 2048 * 2000, 2048 * 1200)):
+for n in ([int(v) for v in os.environ["PERF_N"].split(",")] if os.environ.get("PERF_N") else (1 << 22, 1 << 21, 1 << 20, 2048 * 1920, 2048 * 1000, 2048 * 1536, 2048 * 1280, 2048 * 1080, 2048 * 768, 2048 * 960, 2048 * 2000, 2048 * 1200)):
     hm = buf.numel() // n
     x = buf[:hm * n].reshape(hm, n)
     y = torch.zeros(hm, n // 2 + 1, dtype=torch.complex128, device="cuda")
